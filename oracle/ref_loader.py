@@ -1,0 +1,186 @@
+"""Import the reference's own PyTorch modules for the hot path, on CPU.
+
+TEST INFRASTRUCTURE — build container only.  `/root/reference` is never copied
+and does not exist on the GPU box; everything here skips cleanly when it is
+absent.  The reference needs third-party packages that are not installed
+(detectron2, timm, fvcore, natten); the handful of symbols the hot-path files
+touch are provided as in-process stand-ins with the documented semantics
+(SURVEY.md §8c).  Nothing from the reference's files is restated here.
+
+Loaded files (all under /root/reference/model/modeling):
+  backbone/swin.py
+  pixel_decoder/msdeformattn.py  (+ ops/modules, ops/functions: CPU grid_sample branch)
+  transformer_decoder/{oneformer_transformer_decoder,transformer,position_encoding}.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF_ROOT = os.environ.get("UENC_REFERENCE_ROOT", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "model", "modeling"))
+
+
+class _ShapeSpec:
+    def __init__(self, channels=None, height=None, width=None, stride=None):
+        self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+
+class _Registry:
+    def __init__(self, name):
+        self._name, self._map = name, {}
+
+    def register(self, obj=None):
+        if obj is None:
+            def deco(o):
+                self._map[o.__name__] = o
+                return o
+            return deco
+        self._map[obj.__name__] = obj
+        return obj
+
+    def get(self, name):
+        return self._map[name]
+
+
+class _DropPath(nn.Module):
+    """timm DropPath: per-sample Bernoulli keep, scaled by 1/keep (train only)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        mask = x.new_empty(shape).bernoulli_(keep)
+        return x * mask / keep
+
+
+class _Conv2d(nn.Conv2d):
+    """detectron2.layers.Conv2d: conv -> optional norm -> optional activation."""
+
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def _get_norm(norm, out_channels):
+    if norm is None or norm == "":
+        return None
+    if norm == "GN":
+        return nn.GroupNorm(32, out_channels)
+    raise NotImplementedError(norm)
+
+
+def _configurable(init_func=None, *, from_config=None):
+    # explicit-kwargs construction only: the decorator is the identity
+    if init_func is not None:
+        return init_func
+    return lambda f: f
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_installed = False
+_saved = {}
+
+
+def _install_stubs():
+    global _installed
+    if _installed:
+        return
+    to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+    trunc_normal_ = lambda t, std=1.0, **kw: nn.init.trunc_normal_(t, std=std)
+    _mod("timm")
+    _mod("timm.models")
+    _mod("timm.models.layers", DropPath=_DropPath, to_2tuple=to_2tuple, trunc_normal_=trunc_normal_)
+    backbone_reg, seg_reg = _Registry("BACKBONE"), _Registry("SEM_SEG_HEADS")
+    _mod("detectron2")
+    _mod("detectron2.modeling", BACKBONE_REGISTRY=backbone_reg, Backbone=nn.Module,
+         ShapeSpec=_ShapeSpec, SEM_SEG_HEADS_REGISTRY=seg_reg)
+    _mod("detectron2.config", configurable=_configurable)
+    _mod("detectron2.layers", Conv2d=_Conv2d, ShapeSpec=_ShapeSpec, get_norm=_get_norm, DeformConv=None)
+    _mod("detectron2.utils")
+    _mod("detectron2.utils.registry", Registry=_Registry)
+    _mod("fvcore")
+    _mod("fvcore.nn")
+    _mod("fvcore.nn.weight_init", c2_xavier_fill=lambda m: None, c2_msra_fill=lambda m: None)
+    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+    # package shells whose __path__ points into the reference, bypassing the
+    # __init__.py files that drag in natten / datasets / evaluation.
+    base = os.path.join(REF_ROOT, "model")
+    for name, sub in [
+        ("model", ""),
+        ("model.modeling", "modeling"),
+        ("model.modeling.backbone", "modeling/backbone"),
+        ("model.modeling.transformer_decoder", "modeling/transformer_decoder"),
+        ("model.modeling.pixel_decoder", "modeling/pixel_decoder"),
+        ("model.modeling.pixel_decoder.ops", "modeling/pixel_decoder/ops"),
+        ("model.modeling.pixel_decoder.ops.functions", "modeling/pixel_decoder/ops/functions"),
+        ("model.modeling.pixel_decoder.ops.modules", "modeling/pixel_decoder/ops/modules"),
+    ]:
+        _saved[name] = sys.modules.get(name)
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(base, sub)]
+        sys.modules[name] = m
+    _installed = True
+
+
+def _load(modname, relpath):
+    if modname in sys.modules and getattr(sys.modules[modname], "__file__", None):
+        return sys.modules[modname]
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_ROOT, "model", relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def load():
+    """Returns a namespace with the reference classes used by the goldens."""
+    assert available(), "reference tree not present"
+    _install_stubs()
+    ns = types.SimpleNamespace()
+    swin = _load("model.modeling.backbone.swin", "modeling/backbone/swin.py")
+    func = _load("model.modeling.pixel_decoder.ops.functions.ms_deform_attn_func",
+                 "modeling/pixel_decoder/ops/functions/ms_deform_attn_func.py")
+    sys.modules["model.modeling.pixel_decoder.ops.functions"].ms_deform_attn_func = func
+    mods = _load("model.modeling.pixel_decoder.ops.modules.ms_deform_attn",
+                 "modeling/pixel_decoder/ops/modules/ms_deform_attn.py")
+    sys.modules["model.modeling.pixel_decoder.ops.modules"].MSDeformAttn = mods.MSDeformAttn
+    pe = _load("model.modeling.transformer_decoder.position_encoding",
+               "modeling/transformer_decoder/position_encoding.py")
+    tr = _load("model.modeling.transformer_decoder.transformer",
+               "modeling/transformer_decoder/transformer.py")
+    pix = _load("model.modeling.pixel_decoder.msdeformattn", "modeling/pixel_decoder/msdeformattn.py")
+    dec = _load("model.modeling.transformer_decoder.oneformer_transformer_decoder",
+                "modeling/transformer_decoder/oneformer_transformer_decoder.py")
+    ns.swin, ns.msda_func, ns.msda_mod, ns.pe, ns.transformer, ns.pixdec, ns.dec = swin, func, mods, pe, tr, pix, dec
+    ns.ShapeSpec = _ShapeSpec
+    return ns
