@@ -1,0 +1,148 @@
+"""HIP kernels vs a plain fp32 PyTorch statement of the same op (GPU box, through the C ABI).
+
+Tolerances: operands are bf16 (8 significand bits, rel. rounding 2^-9) with fp32 accumulation, so a
+K-term dot product of O(1) values carries ~2^-9 * sqrt(K) absolute error; outputs stored as bf16
+add one more 2^-9 relative rounding.  References are computed in fp32 from the *bf16-rounded*
+operands so only accumulation order and the output rounding differ.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from uenc import kernels
+    return kernels
+
+
+def _r(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _close(got, want, atol, rtol):
+    torch.testing.assert_close(got.float().cpu(), want.float().cpu(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (256, 384, 192), (200, 100, 72), (1000, 576, 192), (77, 20, 256), (16, 3072, 768)])
+@pytest.mark.parametrize("a_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt_plain(K, M, N, K_, a_dtype):
+    a = _r(M, K_, seed=1, dtype=a_dtype)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias = _r(N, seed=3)
+    want = a.to(torch.bfloat16).float() @ w.float().t() + bias
+    got = K.gemm_nt(a, w, bias=bias, out_dtype=torch.float32)
+    _close(got, want, 2e-3, 2e-3)
+    got16 = K.gemm_nt(a, w, bias=bias, out_dtype=torch.bfloat16)
+    _close(got16, want, 2e-2, 1e-2)
+
+
+def test_gemm_nt_asymmetric_identity(K):
+    # A = I, asymmetric W: catches a transposed fragment / C-write (cdna_hip_programming.md §3)
+    n = 128
+    a = torch.eye(n, dtype=torch.bfloat16).cuda()
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(torch.bfloat16).cuda()
+    got = K.gemm_nt(a, w, out_dtype=torch.float32)
+    _close(got, w.float().t(), 0, 0)
+
+
+def test_gemm_nt_epilogues(K):
+    M, N, K_ = 300, 256, 128
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias = _r(N, seed=3)
+    pre = a.float() @ w.float().t() + bias
+    pre_out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    got = K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_GELU, aux_out=pre_out)
+    _close(got, torch.nn.functional.gelu(pre), 2e-2, 1e-2)
+    _close(pre_out, pre, 2e-2, 1e-2)
+    _close(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RELU), pre.relu(), 2e-2, 1e-2)
+    res = _r(M, N, seed=4)
+    _close(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=torch.float32), pre + res, 2e-3, 2e-3)
+    # in-place residual update (aux aliases out)
+    res2 = res.clone()
+    K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res2, out=res2)
+    _close(res2, pre + res, 2e-3, 2e-3)
+    saved = _r(M, N, seed=5, dtype=torch.bfloat16)
+    x = saved.float().requires_grad_()
+    torch.nn.functional.gelu(x).sum().backward()
+    _close(K.gemm_nt(a, w, epilogue=K.EPI_MUL_DGELU, aux=saved), (pre - bias) * x.grad, 3e-2, 2e-2)
+    _close(K.gemm_nt(a, w, epilogue=K.EPI_MUL_DRELU, aux=saved), (pre - bias) * (saved.float() > 0), 3e-2, 2e-2)
+
+
+def test_gemm_nt_splitk_and_strided(K):
+    M, N, K_ = 150, 256, 4096
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    want = a.float() @ w.float().t()
+    _close(K.gemm_nt(a, w, out_dtype=torch.float32, splitk=8), want, 3e-3, 3e-3)
+    # strided A (a slice of a packed qkv buffer) and strided output
+    big = _r(M, 3 * 256, seed=6, dtype=torch.bfloat16)
+    w2 = _r(64, 256, seed=7, scale=1 / 16, dtype=torch.bfloat16)
+    out = torch.zeros(M, 192, dtype=torch.bfloat16, device="cuda")
+    K.gemm_nt(big[:, 256:512], w2, out=out[:, 64:128])
+    _close(out[:, 64:128], big[:, 256:512].float() @ w2.float().t(), 2e-2, 1e-2)
+    assert float(out[:, :64].abs().max()) == 0 and float(out[:, 128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 128), (1000, 192, 576), (4096, 264, 96), (130, 24, 1032)])
+@pytest.mark.parametrize("x_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_tn_wgrad(K, M, N, K_, x_dtype):
+    dy = _r(M, N, seed=1, dtype=torch.bfloat16)
+    x = _r(M, K_, seed=2, dtype=x_dtype)
+    dw = _r(N, K_, seed=3)
+    db = _r(N, seed=4)
+    want_w = dw + dy.float().t() @ x.to(torch.bfloat16).float()
+    want_b = db + dy.float().sum(0)
+    K.gemm_tn(dy, x, dw, db)
+    tol = 4e-3 * (M ** 0.5)
+    _close(dw, want_w, tol, 2e-3)
+    _close(db, want_b, tol, 2e-3)
+
+
+def test_gemm_tn_asymmetric(K):
+    # dy = I (M = N): dW must equal X exactly
+    n = 128
+    dy = torch.eye(n, dtype=torch.bfloat16).cuda()
+    x = (torch.arange(n * 64, dtype=torch.float32).reshape(n, 64) % 253 - 126).to(torch.bfloat16).cuda()
+    dw = torch.zeros(n, 64, device="cuda")
+    K.gemm_tn(dy, x, dw, None)
+    _close(dw, x.float(), 0, 0)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 96), (333, 192), (64, 256), (50, 768), (20, 1536), (9, 3072), (5, 6144)])
+def test_layernorm_fwd_bwd(K, M, C):
+    x = _r(M, C, seed=1, scale=2.0) + 0.5
+    res = _r(M, C, seed=2)
+    gamma = 1 + 0.1 * _r(C, seed=3)
+    beta = 0.1 * _r(C, seed=4)
+    xr = (x + res).requires_grad_()
+    want = torch.nn.functional.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    y, h, stats = K.layernorm_fwd(x, gamma, beta, res=res, out_dtype=torch.float32, want_h=True)
+    _close(h, xr, 1e-6, 1e-6)
+    _close(y, want, 2e-5, 2e-5)
+    y16, _, _ = K.layernorm_fwd(x, gamma, beta, res=res, out_dtype=torch.bfloat16)
+    _close(y16, want, 2e-2, 1e-2)
+    dy = _r(M, C, seed=5)
+    gam = gamma.clone().requires_grad_()
+    bet = beta.clone().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (C,), gam, bet, 1e-5).backward(dy)
+    dres = _r(M, C, seed=6)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = K.layernorm_bwd(dy, h, stats, gamma, dres=dres, dgamma=dg, dbeta=db)
+    _close(dx, xr.grad + dres, 2e-4, 1e-4)
+    _close(dg, gam.grad, 1e-3, 1e-4)
+    _close(db, bet.grad, 1e-3, 1e-4)
+    # bf16 gradient input
+    dx16 = K.layernorm_bwd(dy.to(torch.bfloat16), h, stats, gamma)
+    _close(dx16, xr.grad, 3e-2, 2e-2)
+
+
+def test_casts(K):
+    w = _r(96, 200, seed=1)
+    _close(K.cast_bf16(w), w.to(torch.bfloat16), 0, 0)
+    _close(K.cast_transpose_bf16(w), w.t().to(torch.bfloat16), 0, 0)
+    b = _r(20, seed=2)
+    _close(K.cast_bf16(b), b.to(torch.bfloat16), 0, 0)

@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of libuenc_hip.so.
+// Wave = 64 lanes; MFMA = v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define UENC_OK 0
+#define UENC_EINVAL (-1)
+
+#define UENC_CHECK_ARG(cond) \
+    do {                     \
+        if (!(cond)) return UENC_EINVAL; \
+    } while (0)
+
+#define UENC_LAUNCH_RET()                       \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        return e__ == hipSuccess ? UENC_OK : (int)e__; \
+    } while (0)
+
+// dtype tags used across the C ABI
+enum { UENC_F32 = 0, UENC_BF16 = 1 };
+
+// D = A(16x32) * B(32x16) + C, bf16 in / fp32 acc.
+//  A fragment: lane l holds A[row l&15][k = 8*(l>>4) .. +7]
+//  B fragment: lane l holds B[k = 8*(l>>4) .. +7][col l&15]
+//  C/D:        lane l, reg r holds D[row 4*(l>>4)+r][col l&15]
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) {  // exact erf form (torch.nn.GELU default)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ bf16x8 cvt8(const float4& a, const float4& b) {
+    bf16x8 r;
+    r[0] = (bf16)a.x; r[1] = (bf16)a.y; r[2] = (bf16)a.z; r[3] = (bf16)a.w;
+    r[4] = (bf16)b.x; r[5] = (bf16)b.y; r[6] = (bf16)b.z; r[7] = (bf16)b.w;
+    return r;
+}
+
+// XCD-aware remap of a 1-D block id: consecutive hardware block ids are dealt round-robin over
+// the 8 XCDs (each with a private L2); give every XCD one contiguous chunk of logical tiles so
+// tiles that share an operand panel hit the same L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

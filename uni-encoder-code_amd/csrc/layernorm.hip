@@ -1,0 +1,215 @@
+// LayerNorm forward / backward over the channel dimension, one 64-lane wave per token row.
+//
+// Covers norm1 / norm2 / PatchMerging.norm / patch_embed.norm / norm{i} of the Swin backbone
+// (reference model/modeling/backbone/swin.py:247, 293, 334, 492, 673) and every post-norm
+// "x = LN(x + sublayer(x))" of the pixel decoder and transformer decoder
+// (pixel_decoder/msdeformattn.py:136-137, 128-129; transformer_decoder/transformer.py:268-297;
+// oneformer_transformer_decoder.py:66-67, 126-127, 184-185), with the residual add fused.
+//
+// HBM-bound: a row is read once (16-byte loads, kept in registers), statistics by wave shuffles,
+// output written once.  Algorithmic bytes per row: C * (in + [res] + out [+ h_out]) element sizes.
+#include "common.h"
+
+struct LnFwd {
+    const void* x; int x_f32;
+    const void* res; int res_f32;     // optional residual added before the norm
+    float* h_out;                     // optional: x + res (fp32), the tensor that is normalised
+    const float* gamma; const float* beta;
+    void* y; int y_f32;
+    float2* stats;                    // optional (mean, rstd) per row
+    long M; int C; float eps;
+};
+
+__device__ __forceinline__ float4 load4(const void* base, int is_f32, long idx) {
+    if (is_f32) return *(const float4*)((const float*)base + idx);
+    const bf16x4 v = *(const bf16x4*)((const bf16*)base + idx);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4(void* base, int is_f32, long idx, float4 v) {
+    if (is_f32) { *(float4*)((float*)base + idx) = v; return; }
+    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *(bf16x4*)((bf16*)base + idx) = o;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const float invC = 1.0f / (float)p.C;
+    for (long row = wave0; row < p.M; row += nwaves) {
+        float4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) {
+                v[i] = load4(p.x, p.x_f32, row * p.C + c);
+                if (p.res != nullptr) {
+                    const float4 r = load4(p.res, p.res_f32, row * p.C + c);
+                    v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
+                }
+                if (p.h_out != nullptr) *(float4*)(p.h_out + row * p.C + c) = v[i];
+                s += v[i].x + v[i].y + v[i].z + v[i].w;
+            } else {
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) {
+                const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += a * a + b * b + cc * cc + d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
+        if (p.stats != nullptr && lane == 0) p.stats[row] = make_float2(mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) {
+                const float4 g = *(const float4*)(p.gamma + c), b = *(const float4*)(p.beta + c);
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * g.x + b.x;
+                o.y = (v[i].y - mean) * rstd * g.y + b.y;
+                o.z = (v[i].z - mean) * rstd * g.z + b.z;
+                o.w = (v[i].w - mean) * rstd * g.w + b.w;
+                store4(p.y, p.y_f32, row * p.C + c, o);
+            }
+        }
+    }
+}
+
+extern "C" int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtype, float* h_out,
+                                  const float* gamma, const float* beta, void* y, int y_dtype, float* stats,
+                                  long M, int C, float eps, hipStream_t stream) {
+    UENC_CHECK_ARG(x && gamma && beta && y && M > 0 && C > 0 && C % 4 == 0 && C <= 6144);
+    LnFwd p;
+    p.x = x; p.x_f32 = (x_dtype == UENC_F32); p.res = res; p.res_f32 = (res_dtype == UENC_F32);
+    p.h_out = h_out; p.gamma = gamma; p.beta = beta; p.y = y; p.y_f32 = (y_dtype == UENC_F32);
+    p.stats = (float2*)stats; p.M = M; p.C = C; p.eps = eps;
+    long blocks = (M + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    const int nv = (C + 255) / 256;
+    dim3 grid((unsigned)blocks), block(256);
+    if (nv <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, p);
+    else if (nv <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, p);
+    else if (nv <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, p);
+    else if (nv <= 8) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, stream, p);
+    else if (nv <= 16) hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(ln_fwd_kernel<24>, grid, block, 0, stream, p);
+    UENC_LAUNCH_RET();
+}
+
+// backward:  xhat = (h - mean) * rstd ;  g = dy * gamma
+//   dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) [+ dres]
+//   dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy
+struct LnBwd {
+    const void* dy; int dy_f32;
+    const void* h; int h_f32;
+    const float2* stats;
+    const float* gamma;
+    const float* dres;               // optional fp32 gradient arriving on the skip path
+    void* dx; int dx_f32;
+    float* dgamma; float* dbeta;     // accumulated (atomicAdd)
+    long M; int C;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [2][C] block partials of dgamma / dbeta
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const float invC = 1.0f / (float)p.C;
+    for (int c = threadIdx.x; c < 2 * p.C; c += 256) sh[c] = 0.f;
+    __syncthreads();
+    float4 ag[NV], ab[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = ag[i];
+        const int c = lane * 4 + i * 256;
+        gm[i] = c < p.C ? *(const float4*)(p.gamma + c) : ag[i];
+    }
+    for (long row = wave0; row < p.M; row += nwaves) {
+        const float2 st = p.stats[row];
+        float4 d[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) {
+                d[i] = load4(p.dy, p.dy_f32, row * p.C + c);
+                const float4 hv = load4(p.h, p.h_f32, row * p.C + c);
+                xh[i] = make_float4((hv.x - st.x) * st.y, (hv.y - st.x) * st.y, (hv.z - st.x) * st.y, (hv.w - st.x) * st.y);
+                ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+                ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+                d[i].x *= gm[i].x; d[i].y *= gm[i].y; d[i].z *= gm[i].z; d[i].w *= gm[i].w;
+                s1 += d[i].x + d[i].y + d[i].z + d[i].w;
+                s2 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+            }
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) {
+                float4 o;
+                o.x = st.y * (d[i].x - s1 - xh[i].x * s2);
+                o.y = st.y * (d[i].y - s1 - xh[i].y * s2);
+                o.z = st.y * (d[i].z - s1 - xh[i].z * s2);
+                o.w = st.y * (d[i].w - s1 - xh[i].w * s2);
+                if (p.dres != nullptr) {
+                    const float4 r = *(const float4*)(p.dres + row * p.C + c);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                store4(p.dx, p.dx_f32, row * p.C + c, o);
+            }
+        }
+    }
+    if (p.dgamma != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) {
+                atomicAdd(&sh[c + 0], ag[i].x); atomicAdd(&sh[c + 1], ag[i].y);
+                atomicAdd(&sh[c + 2], ag[i].z); atomicAdd(&sh[c + 3], ag[i].w);
+                atomicAdd(&sh[p.C + c + 0], ab[i].x); atomicAdd(&sh[p.C + c + 1], ab[i].y);
+                atomicAdd(&sh[p.C + c + 2], ab[i].z); atomicAdd(&sh[p.C + c + 3], ab[i].w);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.C; c += 256) {   // 256 contiguous bytes per wave-instruction
+            atomicAdd(p.dgamma + c, sh[c]);
+            atomicAdd(p.dbeta + c, sh[p.C + c]);
+        }
+    }
+}
+
+extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats,
+                                  const float* gamma, const float* dres, void* dx, int dx_dtype, float* dgamma,
+                                  float* dbeta, long M, int C, hipStream_t stream) {
+    UENC_CHECK_ARG(dy && h && stats && gamma && dx && M > 0 && C > 0 && C % 4 == 0 && C <= 6144);
+    UENC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
+    LnBwd p;
+    p.dy = dy; p.dy_f32 = (dy_dtype == UENC_F32); p.h = h; p.h_f32 = (h_dtype == UENC_F32);
+    p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32);
+    p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C;
+    long blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    const int nv = (C + 255) / 256;
+    const size_t shm = (size_t)2 * C * sizeof(float);
+    dim3 grid((unsigned)blocks), block(256);
+    if (nv <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, shm, stream, p);
+    else if (nv <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, shm, stream, p);
+    else if (nv <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, shm, stream, p);
+    else if (nv <= 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, shm, stream, p);
+    else if (nv <= 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, shm, stream, p);
+    else hipLaunchKernelGGL(ln_bwd_kernel<24>, grid, block, shm, stream, p);
+    UENC_LAUNCH_RET();
+}
