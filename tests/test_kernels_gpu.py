@@ -146,3 +146,49 @@ def test_casts(K):
     _close(K.cast_transpose_bf16(w), w.t().to(torch.bfloat16), 0, 0)
     b = _r(20, seed=2)
     _close(K.cast_bf16(b), b.to(torch.bfloat16), 0, 0)
+
+
+def _window_attn_ref(qkv, qkv_bias, table, H, W, ws, shift, nH):
+    """fp32 statement of the attention core on (B, H*W, 3C) qkv, padding slots = bias; uses the oracle's layout."""
+    from oracle import torch_ref as T
+    B, L, C3 = qkv.shape
+    C, hd = C3 // 3, C3 // 3 // nH
+    src, rid = T.window_layout(H, W, ws, shift)
+    src, rid = src.to(qkv.device), rid.to(qkv.device)
+    nW, N = src.shape
+    z = torch.cat([qkv, qkv_bias.view(1, 1, C3).expand(B, 1, C3)], 1)
+    w = z[:, src.reshape(-1)].view(B * nW, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = w[0], w[1], w[2]
+    attn = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    bias = table[T.relative_position_index(ws).reshape(-1).to(qkv.device)].view(N, N, nH).permute(2, 0, 1)
+    attn = attn + bias[None]
+    if shift > 0:
+        m = (rid[:, :, None] != rid[:, None, :]).float() * -100.0
+        attn = (attn.view(B, nW, nH, N, N) + m[None, :, None]).view(B * nW, nH, N, N)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B, nW * N, C)
+    y = o.new_zeros(B, L + 1, C)
+    y[:, src.reshape(-1)] = o
+    return y[:, :L]
+
+
+@pytest.mark.parametrize("ws,H,W,nH,shift", [(7, 24, 40, 3, 0), (7, 24, 40, 3, 3), (12, 20, 30, 2, 0), (12, 20, 30, 2, 6),
+                                              (12, 24, 36, 1, 6), (3, 7, 8, 1, 1), (5, 9, 11, 2, 2), (8, 16, 16, 1, 4)])
+def test_window_attention_fwd_bwd(K, ws, H, W, nH, shift):
+    B, C = 2, nH * 32
+    qkv = _r(B, H * W, 3 * C, seed=1, scale=1.5, dtype=torch.bfloat16)
+    qb = _r(3 * C, seed=2, scale=0.5, dtype=torch.bfloat16)
+    table = _r((2 * ws - 1) ** 2, nH, seed=3, scale=0.5)
+    bq, bk = K.relpos_expand(table, ws)
+    out = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), qb, bq, ws, shift, 32 ** -0.5)
+    q32 = qkv.float().requires_grad_()
+    b32 = qb.float().requires_grad_()
+    t32 = table.clone().requires_grad_()
+    want = _window_attn_ref(q32, b32, t32, H, W, ws, shift, nH)
+    _close(out.view(B, H * W, C), want, 3e-2, 2e-2)
+    do = _r(B, H * W, C, seed=4, dtype=torch.bfloat16)
+    want.backward(do.float())
+    dqkv, dtab, dpad = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), qb, bq, bk, out, do.view(B, H, W, C), ws, shift, 32 ** -0.5)
+    gs = float(q32.grad.abs().max())
+    _close(dqkv.view(B, H * W, 3 * C), q32.grad, 3e-2 * gs, 3e-2)
+    _close(dtab.t(), t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
+    _close(dpad, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)

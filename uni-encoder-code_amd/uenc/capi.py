@@ -26,6 +26,10 @@ _SIGNATURES = {
     "uenc_gemm_tn": [c_p, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p],
     "uenc_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p],
+    "uenc_window_attn_np": [c_i],
+    "uenc_relpos_expand": [c_p, c_p, c_p, c_i, c_i, c_p],
+    "uenc_window_attn_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 }
 
 

@@ -119,3 +119,43 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
                                  ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, stream_ptr()),
           "layernorm_bwd")
     return dx
+
+
+def relpos_expand(table: torch.Tensor, ws: int):
+    """relative_position_bias_table ((2ws-1)^2, nH) fp32 -> dense (nH, NP, NP) in query-major and key-major order."""
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] == (2 * ws - 1) ** 2
+    nH = table.shape[1]
+    NP = lib.uenc_window_attn_np(ws)
+    bq = torch.empty((nH, NP, NP), dtype=torch.float32, device=table.device)
+    bk = torch.empty_like(bq)
+    check(lib.uenc_relpos_expand(table.data_ptr(), bq.data_ptr(), bk.data_ptr(), nH, ws, stream_ptr()), "relpos_expand")
+    return bq, bk
+
+
+def window_attn_fwd(qkv: torch.Tensor, qkv_bias16: torch.Tensor, bias_q: torch.Tensor, ws: int, shift: int,
+                    scale: float) -> torch.Tensor:
+    """qkv (B, H, W, 3C) bf16 -> attention output (B, H, W, C) bf16 (before proj).  head_dim is 32."""
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv_bias16.dtype == torch.bfloat16
+    assert qkv_bias16.numel() == C3 and C % 32 == 0 and bias_q.shape[0] == C // 32
+    out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=qkv.device)
+    check(lib.uenc_window_attn_fwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), out.data_ptr(), B, H, W, C,
+                                   C // 32, ws, shift, float(scale), stream_ptr()), "window_attn_fwd")
+    return out
+
+
+def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, shift: int, scale: float):
+    """Returns dqkv (B,H,W,3C) bf16, dtab (nH,(2ws-1)^2) fp32, dbias_pad (3C) fp32 (padding-slot share of qkv.bias grad)."""
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    nH = C // 32
+    assert d_out.dtype == torch.bfloat16 and d_out.is_contiguous() and d_out.shape == (B, H, W, C)
+    assert o_saved.dtype == torch.bfloat16 and o_saved.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    dtab = torch.zeros((nH, (2 * ws - 1) ** 2), dtype=torch.float32, device=qkv.device)
+    dpad = torch.zeros((C3,), dtype=torch.float32, device=qkv.device)
+    check(lib.uenc_window_attn_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), bias_k.data_ptr(),
+                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), dtab.data_ptr(), dpad.data_ptr(),
+                                   B, H, W, C, nH, ws, shift, float(scale), stream_ptr()), "window_attn_bwd")
+    return dqkv, dtab, dpad
