@@ -192,3 +192,52 @@ def test_window_attention_fwd_bwd(K, ws, H, W, nH, shift):
     _close(dqkv.view(B, H * W, 3 * C), q32.grad, 3e-2 * gs, 3e-2)
     _close(dtab.t(), t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
     _close(dpad, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)
+
+
+def test_msdeform_golden(K):
+    """The reference's own forward + autograd gradients (tests/golden/msdeform_core.npz)."""
+    from conftest import load_golden
+    g = load_golden("msdeform_core")
+    shapes = g["shapes"].cuda()
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    value, loc, w, go = (g[k].cuda().contiguous() for k in ("value", "loc", "w", "grad_out"))
+    out = K.msdeform_attn_fwd(value, shapes, start, loc, w)
+    _close(out, g["out"], 1e-5, 1e-5)
+    gv, gl, ga = K.msdeform_attn_bwd(value, shapes, start, loc, w, go)
+    _close(gv, g["grad_value"], 1e-5, 1e-4)
+    _close(ga, g["grad_w"], 1e-5, 1e-4)
+    _close(gl, g["grad_loc"], 2e-4, 1e-4)
+    # bf16 value / bf16 output variant
+    out16 = K.msdeform_attn_fwd(value.to(torch.bfloat16), shapes, start, loc, w, out_dtype=torch.bfloat16)
+    _close(out16, g["out"], 3e-2, 2e-2)
+
+
+def test_msdeform_vs_oracle_random(K):
+    from oracle import torch_ref as T
+    shapes_l = [(5, 9), (10, 18), (20, 36)]
+    S = sum(h * w for h, w in shapes_l)
+    B, Lq, M, D, L, P = 2, S, 8, 32, 3, 4
+    gen = torch.Generator().manual_seed(0)
+    value = torch.randn(B, S, M, D, generator=gen)
+    loc = torch.rand(B, Lq, M, L, P, 2, generator=gen) * 1.2 - 0.1
+    w = torch.rand(B, Lq, M, L, P, generator=gen).view(B, Lq, M, -1).softmax(-1).view(B, Lq, M, L, P)
+    v32, l32, w32 = value.clone().requires_grad_(), loc.clone().requires_grad_(), w.clone().requires_grad_()
+    want = T.ms_deform_attn_core(v32, shapes_l, l32, w32)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    shapes = torch.tensor(shapes_l, dtype=torch.int64).cuda()
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    out = K.msdeform_attn_fwd(value.cuda(), shapes, start, loc.cuda(), w.cuda())
+    _close(out, want, 1e-5, 1e-5)
+    gv, gl, ga = K.msdeform_attn_bwd(value.cuda(), shapes, start, loc.cuda(), w.cuda(), go.cuda())
+    _close(gv, v32.grad, 1e-4, 1e-4)
+    _close(ga, w32.grad, 1e-5, 1e-4)
+    _close(gl, l32.grad, 5e-4, 1e-4)
+
+
+def test_gemm_tn_f32_dy(K):
+    dy = _r(300, 64, seed=1)
+    x = _r(300, 40, seed=2)
+    dw = torch.zeros(64, 40, device="cuda")
+    K.gemm_tn(dy, x, dw, None)
+    _close(dw, dy.to(torch.bfloat16).float().t() @ x.to(torch.bfloat16).float(), 5e-2, 2e-3)

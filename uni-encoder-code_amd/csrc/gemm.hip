@@ -233,7 +233,7 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
 // contiguous bytes (MI355X_MICROARCH.md "Global float atomics": the full-rate shape).
 // ---------------------------------------------------------------------------------------------
 struct GemmTN {
-    const bf16* dY; long ldy;
+    const void* dY; int dy_f32; long ldy;
     const void* X; int x_f32; long ldx;
     float* dW; long ldw;
     float* db;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
         if (role == 0) {
             const int col = n0 + cb * 8;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) rin[r] = load_row8(p.dY, 0, p.ldy, mrow + r, mend, col, p.N);
+            for (int r = 0; r < 8; ++r) rin[r] = load_row8(p.dY, p.dy_f32, p.ldy, mrow + r, mend, col, p.N);
         } else {
             const int col = k0 + cb * 8;
 #pragma unroll
@@ -371,14 +371,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
-extern "C" int uenc_gemm_tn(const void* dY, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw, float* db,
-                            int M, int N, int K, int splitm, hipStream_t stream) {
+extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
+                            float* db, int M, int N, int K, int splitm, hipStream_t stream) {
     UENC_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0);
-    UENC_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0);
+    UENC_CHECK_ARG(N % 8 == 0 && K % 8 == 0);
+    UENC_CHECK_ARG(dy_dtype == UENC_F32 ? (ldy % 4 == 0) : (dy_dtype == UENC_BF16 && ldy % 8 == 0));
     UENC_CHECK_ARG(x_dtype == UENC_F32 ? (ldx % 4 == 0) : (x_dtype == UENC_BF16 && ldx % 8 == 0));
     UENC_CHECK_ARG(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0);
     GemmTN p;
-    p.dY = (const bf16*)dY; p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
+    p.dY = dY; p.dy_f32 = (dy_dtype == UENC_F32); p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
     p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
     p.tiles_n = (N + BN - 1) / BN; p.tiles_k = (K + BM - 1) / BM;
     const int mt = (M + BK - 1) / BK;

@@ -80,11 +80,11 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[to
     _mat(dy, "dy"); _mat(x, "x"); _mat(dw, "dw")
     M, N = dy.shape
     M2, K = x.shape
-    if M != M2 or dy.dtype != torch.bfloat16 or dw.dtype != torch.float32 or dw.shape != (N, K):
+    if M != M2 or dw.dtype != torch.float32 or dw.shape != (N, K):
         raise capi.UencError(f"gemm_tn: dy {tuple(dy.shape)} x {tuple(x.shape)} dw {tuple(dw.shape)}")
     if db is not None:
         assert db.dtype == torch.float32 and db.numel() == N and db.is_contiguous()
-    check(lib.uenc_gemm_tn(dy.data_ptr(), dy.stride(0), x.data_ptr(), dt(x), x.stride(0), dw.data_ptr(), dw.stride(0),
+    check(lib.uenc_gemm_tn(dy.data_ptr(), dt(dy), dy.stride(0), x.data_ptr(), dt(x), x.stride(0), dw.data_ptr(), dw.stride(0),
                            ptr(db), M, N, K, int(splitm), stream_ptr()), "gemm_tn")
 
 
@@ -159,3 +159,34 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
                                    o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), dtab.data_ptr(), dpad.data_ptr(),
                                    B, H, W, C, nH, ws, shift, float(scale), stream_ptr()), "window_attn_bwd")
     return dqkv, dtab, dpad
+
+
+def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.float32):
+    """value (B,S,M,D) fp32|bf16, shapes (L,2) int64, level_start (L) int64, loc (B,Lq,M,L,P,2), attn (B,Lq,M,L,P)
+    -> (B, Lq, M*D).  Same tensor contract as the reference's ms_deform_attn_forward."""
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    for t in (value, shapes, level_start, loc, attn):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise capi.UencError("msdeform_attn: tensors must be contiguous CUDA tensors")
+    assert shapes.dtype == torch.int64 and level_start.dtype == torch.int64
+    assert loc.dtype == torch.float32 and attn.dtype == torch.float32 and attn.shape == (B, Lq, M, L, P)
+    out = torch.empty((B, Lq, M * D), dtype=out_dtype, device=value.device)
+    check(lib.uenc_msdeform_attn_fwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(),
+                                     attn.data_ptr(), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, stream_ptr()),
+          "msdeform_attn_fwd")
+    return out
+
+
+def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out):
+    """-> grad_value (fp32, B,S,M,D), grad_loc, grad_attn (the reference's ms_deform_attn_backward contract)."""
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    assert grad_out.is_contiguous() and grad_out.shape == (B, Lq, M * D)
+    gv = torch.zeros((B, S, M, D), dtype=torch.float32, device=value.device)
+    gl = torch.empty_like(loc)
+    ga = torch.empty_like(attn)
+    check(lib.uenc_msdeform_attn_bwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(),
+                                     attn.data_ptr(), grad_out.data_ptr(), dt(grad_out), gv.data_ptr(), gl.data_ptr(),
+                                     ga.data_ptr(), B, S, M, D, L, Lq, P, stream_ptr()), "msdeform_attn_bwd")
+    return gv, gl, ga
