@@ -176,9 +176,9 @@ def main():
     _save("task_tokens", names=np.array(list(ids.keys())), ids=np.stack(list(ids.values())), task_mlp_out=emb)
 
     # F10: small full model forward + backward through the reference modules
-    scfg = T.SwinCfg(48, (2, 2, 2, 2), (3, 6, 12, 24), 7)
+    scfg = T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7)
     sw = build_ref_swin(ref, scfg)
-    ch = {f"res{i + 2}": 48 * 2 ** i for i in range(4)}
+    ch = {f"res{i + 2}": 64 * 2 ** i for i in range(4)}
     pd = build_ref_pixel_decoder(ref, ch)
     dec = build_ref_decoder(ref)
     g = torch.Generator().manual_seed(30)

@@ -393,7 +393,7 @@ def prediction_heads(out: Tensor, mf: Tensor, size, sd: SD, prefix: str):
 
 
 def transformer_decoder(ms_feats: List[Tensor], mf: Tensor, tasks: Tensor, sd: SD, cfg: HeadCfg,
-                        prefix: str = "sem_seg_head.predictor.") -> Dict[str, object]:
+                        prefix: str = "sem_seg_head.predictor.", forced_masks=None) -> Dict[str, object]:
     """transformer_decoder/oneformer_transformer_decoder.py:405-493 in eval mode (is_train False)."""
     nh, E = cfg.nheads, cfg.hidden_dim
     B = mf.shape[0]
@@ -430,6 +430,8 @@ def transformer_decoder(ms_feats: List[Tensor], mf: Tensor, tasks: Tensor, sd: S
     pc.append(cls); pm.append(masks)
     for i in range(cfg.dec_layers):
         lvl = i % 3
+        if forced_masks is not None:
+            am = forced_masks[i]
         am = am & ~am.all(-1, keepdim=True)                          # :454 un-mask fully blocked rows
         ams.append(am)
         lp = f"{prefix}transformer_cross_attention_layers.{i}"
@@ -467,13 +469,13 @@ def task_embedding(tasks: List[str], sd: SD, cfg: ModelCfg) -> Tensor:
     return _mlp(tok, sd, "task_mlp", 2)
 
 
-def oneformer_forward(batched_inputs: List[dict], sd: SD, cfg: ModelCfg, upsample: bool = True):
+def oneformer_forward(batched_inputs: List[dict], sd: SD, cfg: ModelCfg, upsample: bool = True, forced_masks=None):
     """oneformer_model.py:244-263 (segmentation branch up to the mask upsample; no post-processing)."""
     x = preprocess([b["left_image"] for b in batched_inputs], cfg)
     tasks = task_embedding([b["task"] for b in batched_inputs], sd, cfg)
     feats = swin_backbone(x, sd, cfg.swin)
     mf, _, ms = pixel_decoder(feats, sd, cfg.head)
-    out = transformer_decoder(ms, mf, tasks, sd, cfg.head)
+    out = transformer_decoder(ms, mf, tasks, sd, cfg.head, forced_masks=forced_masks)
     if upsample:
         out["pred_masks_up"] = F.interpolate(out["pred_masks"], size=x.shape[-2:], mode="bilinear",
                                              align_corners=False)

