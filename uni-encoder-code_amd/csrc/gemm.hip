@@ -17,6 +17,7 @@
 // 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7): conflict-free ds_read_b128 fragments
 // and conflict-free ds_write_b128 staging.
 #include "common.h"
+#include "prof.h"
 
 #define BM 128
 #define BN 128
@@ -205,6 +206,8 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
     p.alpha = alpha;
     dim3 grid(p.tiles_m * p.tiles_n, splitk), block(GEMM_THREADS);
+    const bool prof = uenc_prof_on();
+    if (prof) uenc_prof_begin(UENC_PROF_GEMM_NT, 2.0 * M * (double)N * K, stream);
 #define LAUNCH(E, F) hipLaunchKernelGGL((gemm_nt_kernel<E, F>), grid, block, 0, stream, p)
     if (c_dtype == UENC_F32) {
         if (epilogue == EPI_NONE) LAUNCH(EPI_NONE, 1);
@@ -222,6 +225,7 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
         }
     }
 #undef LAUNCH
+    if (prof) uenc_prof_end(stream);
     UENC_LAUNCH_RET();
 }
 
@@ -397,6 +401,9 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     p.mlen = ((mt + splitm - 1) / splitm) * BK;
     splitm = (M + p.mlen - 1) / p.mlen;
     dim3 grid(p.tiles_n * p.tiles_k, splitm), block(GEMM_THREADS);
+    const bool prof = uenc_prof_on();
+    if (prof) uenc_prof_begin(UENC_PROF_GEMM_TN, 2.0 * M * (double)N * K, stream);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, p);
+    if (prof) uenc_prof_end(stream);
     UENC_LAUNCH_RET();
 }

@@ -1,0 +1,61 @@
+// Opt-in per-launch timing of the GEMM kernels with HIP events on the launch stream, so that
+// bench.py can report the dominant kernel's achieved FLOP/s over the timed region without an
+// external profiler.  The only process-global state in the library; off by default (then the
+// hooks are a single predictable branch).  Not thread-safe: one launching thread per process.
+#include <hip/hip_runtime.h>
+#include <vector>
+
+#include "prof.h"
+
+namespace {
+struct Rec { int kind; double flops; hipEvent_t e0, e1; };
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_used = 0;
+
+hipEvent_t get_event() {
+    if (g_pool_used == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_used++];
+}
+}  // namespace
+
+bool uenc_prof_on() { return g_on; }
+
+void uenc_prof_begin(int kind, double flops, hipStream_t stream) {
+    Rec r{kind, flops, get_event(), get_event()};
+    if (r.e0 == nullptr || r.e1 == nullptr) return;
+    (void)hipEventRecord(r.e0, stream);
+    g_recs.push_back(r);
+}
+
+void uenc_prof_end(hipStream_t stream) {
+    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, stream);
+}
+
+extern "C" int uenc_prof_enable(int on) {
+    g_on = (on != 0);
+    g_recs.clear();
+    g_pool_used = 0;
+    return 0;
+}
+
+// Sums over all recorded launches of `kind` (call after synchronising the device).
+extern "C" int uenc_prof_collect(int kind, double* ms_total, double* flops_total, long* launches) {
+    double ms = 0.0, fl = 0.0;
+    long n = 0;
+    for (const Rec& r : g_recs) {
+        if (r.kind != kind) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        ms += t; fl += r.flops; ++n;
+    }
+    if (ms_total) *ms_total = ms;
+    if (flops_total) *flops_total = fl;
+    if (launches) *launches = n;
+    return 0;
+}

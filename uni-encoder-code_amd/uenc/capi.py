@@ -20,6 +20,8 @@ c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 # name -> argtypes; every function returns int unless noted
 _SIGNATURES = {
     "uenc_version": [],
+    "uenc_prof_enable": [c_i],
+    "uenc_prof_collect": [c_i, c_p, c_p, c_p],
     "uenc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
     "uenc_cast_transpose_f32_bf16": [c_p, c_p, c_i, c_i, c_p],
     "uenc_gemm_nt": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_i, c_p],

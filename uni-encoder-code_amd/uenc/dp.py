@@ -1,0 +1,139 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, RCCL all-reduce of gradients.
+
+Replaces the reference's `create_ddp_model(model, broadcast_buffers=False)` (tools/trainers/trainer.py:110,
+torch DDP over NCCL).  The path shards by images only (LayerNorm / GroupNorm, no cross-sample op), so
+the single exchange per step is the gradient all-reduce.
+
+Design for MI355X / xGMI:
+  * gradients live in a few large flat fp32 buckets (default 64 MiB) — the HIP wgrad kernels and
+    autograd both accumulate straight into views of them (`p.grad`), so there is no copy-in/out and a
+    bucket is one contiguous RCCL message (few, large collectives suit the per-link-bound xGMI mesh);
+  * a parameter's gradient is *final* when it has received as many contributions as in a calibration
+    step: the HIP Functions report each in-place accumulation (`ops.set_grad_listener`), autograd-
+    produced gradients report through `register_post_accumulate_grad_hook`; no assumption about module
+    boundaries or engine order is made;
+  * buckets are laid out in the order gradients became final during calibration (true backward
+    order), and a bucket's all-reduce is launched asynchronously (RCCL's stream) the moment its last
+    gradient is final, overlapping the rest of backward;
+  * parameters that never receive a gradient on this path are left out.
+`torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class GradBuckets:
+    def __init__(self, model: nn.Module, bucket_mb: float = 64.0, process_group=None, listen_ops: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.params: List[nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        self._index: Dict[int, int] = {id(p): i for i, p in enumerate(self.params)}
+        self._expected: Optional[List[int]] = None          # contributions per parameter per step
+        self._count = [0] * len(self.params)
+        self._order: List[int] = []                          # calibration: parameters in the order they became final
+        self._calibrating = True
+        self._layout(list(range(len(self.params))))
+        self._works = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._autograd_hook) for p in self.params]
+        if listen_ops:
+            from . import ops
+            ops.set_grad_listener(self.signal)
+
+    # ---- flat storage -----------------------------------------------------------------------
+    def _layout(self, order: List[int]):
+        total = sum(self.params[i].numel() for i in order)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.bucket_ranges, self._bucket_of, self._bucket_pending0 = [], {}, []
+        off = start = 0
+        members = 0
+        for i in order:
+            p = self.params[i]
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[i] = len(self.bucket_ranges)
+            off += n
+            members += 1
+            if off - start >= self.cap:
+                self.bucket_ranges.append((start, off)); self._bucket_pending0.append(members)
+                start, members = off, 0
+        if off > start:
+            self.bucket_ranges.append((start, off)); self._bucket_pending0.append(members)
+        self._pending = list(self._bucket_pending0)
+        self._launched = [False] * len(self.bucket_ranges)
+
+    # ---- readiness signals --------------------------------------------------------------------
+    def _autograd_hook(self, p):
+        self.signal(p)
+
+    def signal(self, p):
+        """One gradient contribution has been accumulated into p.grad."""
+        i = self._index.get(id(p))
+        if i is None:
+            return
+        self._count[i] += 1
+        if self._calibrating:
+            if self._count[i] == 1:
+                self._order.append(i)
+            else:                       # final position = last contribution
+                self._order.remove(i); self._order.append(i)
+            return
+        if self._count[i] == self._expected[i]:
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self._launched[b]:
+                self._launch(b)
+
+    def _launch(self, b: int):
+        self._launched[b] = True
+        if self.world > 1:
+            s, e = self.bucket_ranges[b]
+            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    # ---- step protocol --------------------------------------------------------------------------
+    def zero_grad(self):
+        self.flat.zero_()
+        self._count = [0] * len(self.params)
+        self._pending = list(self._bucket_pending0)
+        self._launched = [False] * len(self.bucket_ranges)
+        self._works = []
+        if self._calibrating:
+            self._order = []
+
+    def finish(self):
+        """After backward: reduce whatever has not been launched, wait, average.  The first call also
+        fixes the bucket layout from the observed gradient order (gradients of this step are reduced first)."""
+        for b in range(len(self.bucket_ranges)):
+            if not self._launched[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        if self._calibrating:
+            self._calibrating = False
+            self._expected = list(self._count)
+            silent = [i for i in range(len(self.params)) if self._count[i] == 0]
+            order = self._order + silent       # parameters that got no gradient go last and never gate a launch
+            old = {i: self.params[i].grad.clone() for i in range(len(self.params))}
+            self._layout(order)
+            for i, gi in old.items():
+                self.params[i].grad.copy_(gi)
+            # silent parameters must not keep a bucket waiting
+            for i in silent:
+                self._bucket_pending0[self._bucket_of[i]] -= 1
+            self._pending = list(self._bucket_pending0)
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        try:
+            from . import ops
+            ops.set_grad_listener(None)
+        except Exception:
+            pass

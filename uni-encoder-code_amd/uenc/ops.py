@@ -77,6 +77,23 @@ class ParamCache:
 CACHE = ParamCache()
 
 
+_GRAD_LISTENER = None
+
+
+def set_grad_listener(fn):
+    """`fn(param)` is called after each in-place accumulation into `param.grad` by a HIP Function
+    (the data-parallel bucket scheduler uses it to know when a gradient is final)."""
+    global _GRAD_LISTENER
+    _GRAD_LISTENER = fn
+
+
+def _notify(*params):
+    if _GRAD_LISTENER is not None:
+        for p in params:
+            if p is not None and p.requires_grad:
+                _GRAD_LISTENER(p)
+
+
 def grad_buf(p: torch.Tensor) -> torch.Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -110,6 +127,7 @@ def _wgrad(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: Optional[tor
             gb = gb[rows[0]:rows[1]]
     if N % 8 == 0 and Kd % 8 == 0 and gw.shape == (N, Kd):
         K.gemm_tn(dy2, x2, gw, gb)
+        _notify(w, b)
         return
     # odd-sized tiny layers (class_embed N=20, task_mlp K=77): zero-padded scratch, then add the slice
     Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
@@ -120,6 +138,7 @@ def _wgrad(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: Optional[tor
     gw.add_(tw[: gw.shape[0], : gw.shape[1]])
     if gb is not None:
         gb.add_(tb[: gb.numel()])
+    _notify(w, b)
 
 
 def _fwd_gemm(x2, w, b, rows, **kw):
@@ -266,6 +285,7 @@ class LayerNormFn(torch.autograd.Function):
         dg = grad_buf(gamma) if gamma.requires_grad else None
         db = grad_buf(beta) if gamma.requires_grad else None
         dx = K.layernorm_bwd(dy.contiguous(), h, stats, gamma.detach(), dgamma=dg, dbeta=db)
+        _notify(gamma, beta)
         dxx = dx if ctx.xdtype == F32 else dx.to(ctx.xdtype)
         dr = None
         if ctx.has_res:
@@ -339,6 +359,8 @@ class SwinBlockFn(torch.autograd.Function):
             grad_buf(table).add_(dtab.t())
         dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
                              dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None)
+        if train:
+            _notify(g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
         return (dx.view(B, L, C),) + (None,) * 19
 
 
