@@ -1,0 +1,114 @@
+/* libuenc_hip.so — C ABI of the MI355X (gfx950) kernels behind the unified-encoder hot path.
+ *
+ * Drop-in boundary.  The reference is a Python / Detectron2 plug-in whose only foreign-function
+ * interface is the pybind11 module `MultiScaleDeformableAttention`
+ * (model/modeling/pixel_decoder/ops/src/vision.cpp:18-21, ms_deform_attn.h:25-66).  Entry points
+ * `uenc_msdeform_attn_{fwd,bwd}` replace exactly that pair with the same tensor contract.  Every other
+ * entry point replaces a group of ATen calls that the reference issues from Python (cited per function);
+ * the Python side (`uni-encoder-code_amd/uenc/kernels.py`, ctypes) binds all of them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only: device pointers are `void*` / typed pointers into HBM,
+ *     sizes are element counts, strides ("ld*") are in elements; no framework types;
+ *   - return 0 = launched, < 0 = invalid argument (shape / alignment / dtype; nothing was launched),
+ *     > 0 = hipError_t from the launch;
+ *   - the caller owns every buffer (inputs, outputs, scratch); the library allocates nothing, never
+ *     synchronises, and launches on the given stream (`hipStream_t`, passed as void*);
+ *   - stateless and re-entrant, with one opt-in exception: the `uenc_prof_*` launch timers;
+ *   - dtype tags: UENC_F32 = 0, UENC_BF16 = 1.  bf16 operands, fp32 accumulation everywhere.
+ *   - gfx950 only.
+ */
+#ifndef UENC_H
+#define UENC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UENC_F32 0
+#define UENC_BF16 1
+
+/* GEMM epilogues */
+#define UENC_EPI_NONE 0       /* C = alpha * (A W^T + bias)                                   */
+#define UENC_EPI_GELU 1       /* C = gelu(.) (erf form); optional aux_out <- pre-activation    */
+#define UENC_EPI_RELU 2       /* C = relu(.)                                                   */
+#define UENC_EPI_RESIDUAL 3   /* C = (.) + aux            aux fp32, may alias C                */
+#define UENC_EPI_MUL_DGELU 4  /* C = (.) * gelu'(aux)     aux bf16 = saved pre-activation      */
+#define UENC_EPI_MUL_DRELU 5  /* C = (.) * (aux > 0)      aux bf16 = saved ReLU output         */
+
+int uenc_version(void);
+const char* uenc_arch(void); /* "gfx950" */
+
+/* ---- casts: fp32 master weights -> bf16 MFMA operands (replaces autocast-style .to(bf16)) ---------- */
+int uenc_cast_f32_bf16(const float* src, void* dst, long n /* multiple of 8 */, void* stream);
+int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C][R] bf16 */, int R, int C, void* stream);
+
+/* ---- Linear layers ---------------------------------------------------------------------------------
+ * C[m][n] = epi(alpha * (sum_k A[m][k] W[n][k] + bias[n])).  A fp32|bf16 [M][K] (lda), W bf16 [N][K] (ldw),
+ * C fp32|bf16 [M][N] (ldc).  K % 8 == 0, N % 4 == 0, 16-byte aligned bases.  splitk > 1 or accumulate != 0
+ * adds into fp32 C with atomics (EPI_NONE only).
+ * Replaces nn.Linear / F.linear / 1x1 Conv2d / einsum("bqc,bchw->bqhw") of
+ *   backbone/swin.py:35-41,138-170,335  pixel_decoder/ops/modules/ms_deform_attn.py:103-125
+ *   pixel_decoder/msdeformattn.py:126-130,237,266,290  transformer_decoder/oneformer_transformer_decoder.py:183,498-500
+ *   and nn.MultiheadAttention's in/out projections (transformer.py:252-253). */
+int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
+                 int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
+                 void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, void* stream);
+
+/* weight / bias gradient of the same Linear:  dW[n][k] += sum_m dY[m][n] X[m][k];  db[n] += sum_m dY[m][n]
+ * (db may be NULL).  dY, X fp32|bf16 row-major; dW, db fp32, accumulated (atomics).  N % 8 == K % 8 == 0.
+ * splitm <= 0 lets the library choose the split of the token dimension.  Replaces autograd's
+ * mm / sum backward of every Linear above. */
+int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
+                 float* db, int M, int N, int K, int splitm, void* stream);
+
+/* ---- LayerNorm over the last dimension (C % 4 == 0, C <= 6144) --------------------------------------
+ * y = LN(x + res) * gamma + beta; optional h_out <- x + res (fp32); optional stats <- (mean, rstd) per row.
+ * Replaces nn.LayerNorm and the preceding residual add of swin.py:247,293,334,492,673,
+ * msdeformattn.py:128-129,136-137, transformer.py:268-297, oneformer_transformer_decoder.py:66-67,126-127,184-185,496. */
+int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtype, float* h_out, const float* gamma,
+                       const float* beta, void* y, int y_dtype, float* stats, long M, int C, float eps, void* stream);
+/* dx = LN'(dy) [+ dres];  dgamma / dbeta accumulated (both NULL to skip). */
+int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats, const float* gamma,
+                       const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* stream);
+
+/* ---- shifted-window attention (head_dim 32, window <= 12) ---------------------------------------------
+ * Replaces F.pad -> torch.roll -> window_partition -> WindowAttention core -> window_reverse -> roll -> crop,
+ * backbone/swin.py:250-289 around :131-171, shift mask of :414-440.
+ * qkv (B,H,W,3C) bf16 = qkv Linear output of the real tokens; qkv_bias (3C) bf16 (value of padding slots);
+ * bias_q / bias_k: expanded relative-position bias from uenc_relpos_expand; out (B,H,W,C) bf16. */
+int uenc_window_attn_np(int ws); /* padded tokens per window = 16 * ceil(ws*ws / 16) */
+int uenc_relpos_expand(const float* table /* ((2ws-1)^2, nH) */, float* bias_q /* (nH,NP,NP) [h][q][key] */,
+                       float* bias_k /* (nH,NP,NP) [h][key][q] */, int nH, int ws, void* stream);
+int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
+                         int C, int nH, int ws, int shift, float scale, void* stream);
+/* dqkv (B,H,W,3C) bf16 written; dtab (nH,(2ws-1)^2) and dbias_pad (3C) fp32 accumulated (caller zeroes). */
+int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
+                         const void* o_saved, const void* d_out, void* dqkv, float* dtab, float* dbias_pad, int B,
+                         int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
+
+/* ---- multi-scale deformable attention: the reference's native op ---------------------------------------
+ * ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+ *   (ops/src/ms_deform_attn.h:25-45, kernel ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304):
+ * value (B,S,M,D) fp32|bf16, shapes (L,2) int64 (H,W), level_start (L) int64, loc (B,Lq,M,L,P,2) fp32,
+ * attn (B,Lq,M,L,P) fp32 -> out (B,Lq,M*D) fp32|bf16.  D in {16,32,64}.  im2col_step is not needed:
+ * one launch covers the batch. */
+int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
+                           const float* loc, const float* attn, void* out, int out_dtype, int B, int S, int M, int D,
+                           int L, int Lq, int P, void* stream);
+/* ms_deform_attn_backward (ms_deform_attn.h:47-66, cuh:306-408): grad_value fp32 accumulated (caller zeroes,
+ * as the reference's at::zeros_like), grad_loc / grad_attn overwritten. */
+int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
+                           const float* loc, const float* attn, const void* grad_out, int go_dtype, float* grad_value,
+                           float* grad_loc, float* grad_attn, int B, int S, int M, int D, int L, int Lq, int P,
+                           void* stream);
+
+/* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
+int uenc_prof_enable(int on); /* also resets */
+int uenc_prof_collect(int kind /* 0 gemm_nt, 1 gemm_tn */, double* ms_total, double* flops_total, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UENC_H */

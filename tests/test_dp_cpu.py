@@ -1,0 +1,97 @@
+"""Data-parallel gradient buckets over gloo, world size 2, on CPU (the N > 1 path of bench.py)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 8))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "uni-encoder-code_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uenc.dp import GradBuckets
+    m = _model()
+    shared = m[2].weight                       # also used a second time below: a multi-contribution parameter
+    gb = GradBuckets(m, bucket_mb=0.004, listen_ops=False)     # ~1k floats per bucket -> several buckets
+    res = []
+    for step in range(3):
+        gb.zero_grad()
+        g = torch.Generator().manual_seed(100 * step + rank)
+        x = torch.randn(5, 16, generator=g)
+        y = m(x)
+        loss = y.square().mean() + shared.square().sum() * x.mean() * 1e-3
+        loss.backward()
+        gb.finish()
+        res.append([p.grad.detach().clone().numpy() for p in m.parameters()])
+        assert all(p.grad.data_ptr() >= gb.flat.data_ptr() for p in m.parameters())
+    q.put((rank, res, len(gb.bucket_ranges)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_mean_of_local_grads():
+    world, port = 2, 29541
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, nbuckets = {}, []
+    try:
+        for _ in range(world):
+            r, res, nb = q.get(timeout=60)
+            out[r] = res
+            nbuckets.append(nb)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(nb >= 2 for nb in nbuckets)
+    # single-process reference: average of the two ranks' local gradients
+    m = _model()
+    shared = m[2].weight
+    for step in range(3):
+        want = None
+        for rank in range(world):
+            m.zero_grad()
+            g = torch.Generator().manual_seed(100 * step + rank)
+            x = torch.randn(5, 16, generator=g)
+            (m(x).square().mean() + shared.square().sum() * x.mean() * 1e-3).backward()
+            gs = [p.grad.clone() for p in m.parameters()]
+            want = gs if want is None else [a + b for a, b in zip(want, gs)]
+        want = [w / world for w in want]
+        for rank in range(world):
+            for a, b in zip(out[rank][step], want):
+                torch.testing.assert_close(torch.from_numpy(a), b, atol=1e-6, rtol=1e-5)
+
+
+def test_single_process_buckets_track_signals():
+    sys.path.insert(0, os.path.join(ROOT, "uni-encoder-code_amd"))
+    from uenc.dp import GradBuckets
+    m = _model()
+    gb = GradBuckets(m, bucket_mb=0.004, listen_ops=False)
+    for _ in range(2):
+        gb.zero_grad()
+        m(torch.randn(4, 16)).sum().backward()
+        gb.finish()
+    assert gb._expected == [1] * len(gb.params) and not gb._calibrating
+    # after calibration the layout follows backward order: the last layer's parameters come first
+    first = gb.params[[i for i, b in gb._bucket_of.items() if b == 0][0]]
+    assert any(first is p for p in m[4].parameters())
+    gb.zero_grad()
+    m(torch.randn(4, 16)).sum().backward()
+    assert all(gb._launched) or gb.world == 1
+    gb.finish()
