@@ -12,51 +12,56 @@
 // (Linear of a zero row), read from `qkv_bias`; they take part as un-masked keys exactly as in the
 // reference and their outputs are dropped.
 //
-// One workgroup per (window, head): WAVES waves, each owning QT 16-query tiles.
-//   S^T[key][q] = K Q^T        MFMA 16x16x32 (head_dim 32 = one k-step), operands straight from L2
-//   softmax over keys          in registers: a lane holds one query column, 4 keys per tile
-//   O^T[d][q]   = V^T P^T      P^T tiles feed the next MFMA as B operand with no lane movement;
-//                              V^T comes from an LDS image [d][key] filled once per workgroup
-// Backward recomputes S in both orientations (key-major for dQ, query-major for dK / dV) so every
-// gradient of a window is produced by its own workgroup: no cross-workgroup reduction except the
-// relative-position table (LDS accumulation, then one contiguous atomic burst per workgroup) and
-// the qkv-bias gradient that padding slots contribute.
-// Algorithmic HBM bytes per token per head-slice: read 3*32*2 (fwd) ; bwd read 5*32*2 + write 3*32*2.
+// One workgroup per (window, head), one wave per 16-token tile (9 waves for a 12x12 window).
+//   1. every thread issues its share of the window's q/k/v(/dO) rows as 16-byte loads back to back
+//      (the whole 27-36 KB of a window-head is in flight at once: HBM-latency is paid once), then
+//      writes them row-major into LDS (64-byte rows, 16-byte chunks XOR-swizzled: conflict-free for
+//      ds_read_b128 fragment reads and for ds_read_b64_tr_b16 transposed reads);
+//   2. S^T[key][q] = K Q^T on MFMA 16x16x32 (head_dim 32 = one k-step): a lane owns one query
+//      column, so softmax is register math + two shuffles; exp2 with log2(e) folded into scale/bias;
+//   3. O^T[d][q] = V^T P^T: P^T tiles are the next MFMA's B operand without lane movement, V^T
+//      fragments come from the row-major V image through the hardware transposing LDS read.
+// Backward recomputes S in both orientations (key-major for dQ, query-major for dK / dV), so every
+// gradient of a window is produced by its own workgroup; the relative-position-table gradient is
+// accumulated in LDS and written as one partial row per workgroup (summed by the caller), the
+// qkv-bias gradient contributed by padding slots uses atomics (few slots).
+// Algorithmic HBM bytes per token per head: fwd read 3*64 + write 64; bwd read 5*64 + write 3*64.
 #include "common.h"
+
+#define LOG2E 1.4426950408889634f
 
 struct WAttn {
     const bf16* qkv;        // (B, H, W, 3C)
     const bf16* qkv_bias;   // (3C) bf16 copy of attn.qkv.bias
-    const float* bias_q;    // (nH, NP, NP) [h][q][key]   expanded relative-position bias, -30000 for key >= N
-    const float* bias_k;    // (nH, NP, NP) [h][key][q]   same, key-major (backward phase B)
+    const float* bias_q;    // (nH, NP, NP) [h][q][key]  log2(e) * relative-position bias, -30000 for key >= N
+    const float* bias_k;    // (nH, NP, NP) [h][key][q]  same, key-major (backward phase B)
     bf16* out;              // (B, H, W, C) attention output (before proj)
     // backward only
     const bf16* o_saved;    // forward output
     const bf16* d_out;      // (B, H, W, C)
     bf16* dqkv;             // (B, H, W, 3C)
-    float* dtab;            // (nH, (2ws-1)^2) accumulated
-    float* dbias_pad;       // (3C) accumulated: gradient reaching qkv.bias through padding slots
+    float* dtab_ws;         // (nWinTotal * nH, (2ws-1)^2 + 96) per-workgroup partials (overwritten): table gradient, then
+                            // the q|k|v (3 x 32) qkv-bias gradient that reaches this head through padding slots
     int B, H, W, C, nH, ws, shift, Hp, Wp, nWw, nWin, nWinTotal, N;
     float scale;
 };
 
 template <int NTILES>
 struct WCfg {
-    static constexpr int WAVES = (NTILES + 2) / 3;
-    static constexpr int QT = (NTILES + WAVES - 1) / WAVES;
+    static constexpr int WAVES = NTILES;
+    static constexpr int NTH = 64 * NTILES;
     static constexpr int NP = NTILES * 16;
-    static constexpr int NKB = (NTILES + 1) / 2;       // 32-key blocks
-    static constexpr int KP = NKB * 32 > 128 ? 264 : 136;   // LDS row pitch (elements): 16 B mod 256 B
+    static constexpr int NKB = (NTILES + 1) / 2;   // 32-key blocks
+    static constexpr int NK2 = NKB * 32;           // rows staged (zero / bias filled beyond N)
 };
 
 __device__ __forceinline__ int region3(int v, int P, int ws, int shift) { return (v >= P - ws) + (v >= P - shift); }
 
-// token bookkeeping shared by forward and backward: for slot t of this window,
-//   tokoff = flat token index (b*H + h)*W + w, or -1 for a padding slot, or -2 beyond N
-template <int NP>
+// slot bookkeeping: tokoff = flat token index, -1 padding slot, -2 beyond the window's N tokens
+template <int NK2>
 __device__ __forceinline__ void window_slots(const WAttn& p, int b, int wi, int wj, int* tokoff, unsigned char* rid,
                                              unsigned short* yx, int nthreads) {
-    for (int t = threadIdx.x; t < NP; t += nthreads) {
+    for (int t = threadIdx.x; t < NK2; t += nthreads) {
         int off = -2, r = 0, code = 0;
         if (t < p.N) {
             const int ty = t / p.ws, tx = t - ty * p.ws;
@@ -83,140 +88,152 @@ __device__ __forceinline__ void decode_block(const WAttn& p, int& win, int& head
     head = r >> 3;
 }
 
-__device__ __forceinline__ bf16x8 zero8() {
-    bf16x8 z;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
-    return z;
+// LDS image of a [rows][32] bf16 matrix: 64-byte rows, chunk c (16 B) of row r at c ^ ((r >> 1) & 3)
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+
+// fragment of 16 rows x 32 k: lane (row = r0 + (lane & 15), k = 8 * (lane >> 4) ..)
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* img, int r0, int fr, int fg) {
+    return *(const bf16x8*)(img + rm_off(r0 + fr, fg));
 }
 
-// stage rows [key][32 d] (one head slice) of `base` transposed into LDS dst[d][key]
-template <int KP, int NKEYS>
-__device__ __forceinline__ void stage_transposed(bf16* dst, const bf16* base, long rowstride, const bf16* padrow,
-                                                 bool pad_zero, int coloff, const int* tokoff, int nthreads) {
-    for (int idx = threadIdx.x; idx < NKEYS * 4; idx += nthreads) {
-        const int key = idx >> 2, ch = idx & 3;
-        const int tok = tokoff[key];
-        bf16x8 v = zero8();
-        if (tok >= 0) v = *(const bf16x8*)(base + (long)tok * rowstride + coloff + ch * 8);
-        else if (tok == -1 && !pad_zero) v = *(const bf16x8*)(padrow + coloff + ch * 8);
+// transposed fragment for an MFMA A operand A[i = d][k]: d = d0 + (lane & 15); k-slots 0..3 <- rows
+// ra + 4*fg + 0..3, k-slots 4..7 <- rows rb + 4*fg + 0..3 (the order P^T / dS tiles come out of the
+// previous MFMA's accumulators).  Two ds_read_b64_tr_b16.
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* img, int ra, int rb, int d0, int lane) {
+    const int fg = lane >> 4, i = lane & 15, q4 = i >> 2, p4 = i & 3;
+    const int chunk = (d0 >> 3) + (p4 >> 1), sub = (p4 & 1) << 3;
+    const int row_a = ra + 4 * fg + q4, row_b = rb + 4 * fg + q4;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + rm_off(row_a, chunk) + sub));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + rm_off(row_b, chunk) + sub));
+    bf16x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[(ch * 8 + j) * KP + key] = v[j];
+    for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+    return r;
+}
+
+// Bulk staging: NIMG images of NK2 rows x 4 chunks; all loads of a thread are issued before its stores.
+//   src row pointer: tok >= 0 -> base[img] + tok * stride[img]; tok == -1 -> pad[img] (or zeros); tok == -2 -> zeros
+template <int NIMG, int NK2, int NTH>
+__device__ __forceinline__ void stage_images(unsigned char* const (&img)[NIMG], const bf16* const (&base)[NIMG],
+                                             const long (&stride)[NIMG], const bf16* const (&pad)[NIMG], const int* tokoff) {
+    constexpr int PER = (NK2 * 4 + NTH - 1) / NTH;      // chunks per thread per image (1-2)
+    u32x4 v[NIMG][PER];
+    int tok[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int idx = threadIdx.x + it * NTH;
+        tok[it] = idx < NK2 * 4 ? tokoff[idx >> 2] : -2;
     }
+#pragma unroll
+    for (int k = 0; k < NIMG; ++k)
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int ch = (threadIdx.x + it * NTH) & 3;
+            const bf16* src = tok[it] >= 0 ? base[k] + (long)tok[it] * stride[k] : pad[k];
+            v[k][it] = (u32x4){0u, 0u, 0u, 0u};
+            if (tok[it] >= 0 || (tok[it] == -1 && pad[k] != nullptr)) v[k][it] = *(const u32x4*)(src + ch * 8);
+        }
+#pragma unroll
+    for (int k = 0; k < NIMG; ++k)
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = threadIdx.x + it * NTH;
+            if (idx < NK2 * 4) *(u32x4*)(img[k] + rm_off(idx >> 2, idx & 3)) = v[k][it];
+        }
 }
 
 template <int NTILES>
-__global__ __launch_bounds__(64 * WCfg<NTILES>::WAVES) void wattn_fwd_kernel(WAttn p) {
+__global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
     using Cf = WCfg<NTILES>;
-    constexpr int WAVES = Cf::WAVES, QT = Cf::QT, NP = Cf::NP, NKB = Cf::NKB, KP = Cf::KP, NK2 = NKB * 32;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[32 * KP * 2 + NK2 * 4 + NK2];
-    bf16* Vt = (bf16*)smem;
-    int* tokoff = (int*)(smem + 32 * KP * 2);
-    unsigned char* rid = smem + 32 * KP * 2 + NK2 * 4;
+    constexpr int NTH = Cf::NTH, NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * NK2 * 64 + NK2 * 4 + NK2];
+    unsigned char* Qs = smem;
+    unsigned char* Ks = smem + NK2 * 64;
+    unsigned char* Vs = smem + 2 * NK2 * 64;
+    int* tokoff = (int*)(smem + 3 * NK2 * 64);
+    unsigned char* rid = smem + 3 * NK2 * 64 + NK2 * 4;
 
     int win, head;
     decode_block(p, win, head);
     if (win >= p.nWinTotal) return;
     const int b = win / p.nWin, wrem = win - b * p.nWin;
     const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-    const int C = p.C, C3 = 3 * p.C, hoff = head * 32;
+    const int lane = threadIdx.x & 63, qt = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    const int C = p.C, hoff = head * 32;
+    const long C3 = 3 * (long)p.C;
 
-    window_slots<NP>(p, b, wi, wj, tokoff, rid, nullptr, 64 * WAVES);
-    for (int t = NP + threadIdx.x; t < NK2; t += 64 * WAVES) { tokoff[t] = -2; rid[t] = 0; }
+    window_slots<NK2>(p, b, wi, wj, tokoff, rid, nullptr, NTH);
     __syncthreads();
-    stage_transposed<KP, NK2>(Vt, p.qkv, C3, p.qkv_bias, false, 2 * C + hoff, tokoff, 64 * WAVES);
-    __syncthreads();
-
-    auto rowp = [&](int tok) -> const bf16* { return tok >= 0 ? p.qkv + (long)tok * C3 : p.qkv_bias; };
-
-    bf16x8 qf[QT];
-    int qtok[QT];
-#pragma unroll
-    for (int jq = 0; jq < QT; ++jq) {
-        const int qt = wave * QT + jq;
-        qtok[jq] = qt < NTILES ? tokoff[qt * 16 + fr] : -2;
-        qf[jq] = *(const bf16x8*)(rowp(qtok[jq]) + hoff + 8 * fg);
+    {
+        unsigned char* const img[3] = {Qs, Ks, Vs};
+        const bf16* const base[3] = {p.qkv + hoff, p.qkv + C + hoff, p.qkv + 2 * C + hoff};
+        const long stride[3] = {C3, C3, C3};
+        const bf16* const pad[3] = {p.qkv_bias + hoff, p.qkv_bias + C + hoff, p.qkv_bias + 2 * C + hoff};
+        stage_images<3, NK2, NTH>(img, base, stride, pad, tokoff);
     }
-    f32x4 s[NTILES][QT];
+    __syncthreads();
+
+    const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
+    const int qi = qt * 16 + fr;
+    const int qtok = tokoff[qi];
+    const bf16x8 qf = frag_rows(Qs, qt * 16, fr, fg);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s[NTILES];
+#pragma unroll
+    for (int kt = 0; kt < NTILES; ++kt) s[kt] = mfma16(frag_rows(Ks, kt * 16, fr, fg), qf, zero4);
+
+    const float sc = p.scale * LOG2E;
+    const float* brow = p.bias_q + ((long)head * NP + qi) * NP;
+    const int ridq = rid[qi];
+    float mx = -1e30f;
 #pragma unroll
     for (int kt = 0; kt < NTILES; ++kt) {
-        const bf16x8 kf = *(const bf16x8*)(rowp(tokoff[kt * 16 + fr]) + C + hoff + 8 * fg);
-#pragma unroll
-        for (int jq = 0; jq < QT; ++jq) s[kt][jq] = mfma16(kf, qf[jq], (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
-    float inv[QT];
-#pragma unroll
-    for (int jq = 0; jq < QT; ++jq) {
-        const int qt = wave * QT + jq;
-        const int qi = (qt < NTILES ? qt : 0) * 16 + fr;
-        const int ridq = rid[qi];
-        const float* brow = p.bias_q + ((long)head * NP + qi) * NP;
-        float mx = -1e30f;
-#pragma unroll
-        for (int kt = 0; kt < NTILES; ++kt) {
-            const float4 bb = *(const float4*)(brow + kt * 16 + 4 * fg);
+        const float4 bb = *(const float4*)(brow + kt * 16 + 4 * fg);
+        s[kt][0] = s[kt][0] * sc + bb.x; s[kt][1] = s[kt][1] * sc + bb.y;
+        s[kt][2] = s[kt][2] * sc + bb.z; s[kt][3] = s[kt][3] * sc + bb.w;
+        if (masked) {
             const unsigned rk = *(const unsigned*)(rid + kt * 16 + 4 * fg);
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[kt][jq][r] * p.scale + bv[r];
-                if (p.shift > 0 && (int)((rk >> (8 * r)) & 0xffu) != ridq) v -= 100.0f;
-                s[kt][jq][r] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int r = 0; r < 4; ++r)
+                if ((int)((rk >> (8 * r)) & 0xffu) != ridq) s[kt][r] -= 100.0f * LOG2E;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NTILES; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][jq][r] - mx);
-                s[kt][jq][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        inv[jq] = 1.0f / sum;
+        mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
     }
-    f32x4 o[2][QT];
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int kt = 0; kt < NTILES; ++kt)
 #pragma unroll
-        for (int jq = 0; jq < QT; ++jq) o[dt][jq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) {
+            const float e = exp2f(s[kt][r] - mx);
+            s[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    f32x4 o[2] = {zero4, zero4};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        bf16x8 pb[QT];
+        bf16x8 pb;
 #pragma unroll
-        for (int jq = 0; jq < QT; ++jq) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pb[jq][r] = (bf16)s[2 * kb][jq][r];
-                pb[jq][4 + r] = (2 * kb + 1 < NTILES) ? (bf16)s[(2 * kb + 1 < NTILES) ? 2 * kb + 1 : 0][jq][r] : (bf16)0.f;
-            }
+        for (int r = 0; r < 4; ++r) {
+            pb[r] = (bf16)s[2 * kb][r];
+            pb[4 + r] = (2 * kb + 1 < NTILES) ? (bf16)s[(2 * kb + 1 < NTILES) ? 2 * kb + 1 : 0][r] : (bf16)0.f;
         }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const bf16* vrow = Vt + (dt * 16 + fr) * KP + 32 * kb + 4 * fg;
-            const bf16x4 lo = *(const bf16x4*)vrow, hi = *(const bf16x4*)(vrow + 16);
-            bf16x8 vf;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
-#pragma unroll
-            for (int jq = 0; jq < QT; ++jq) o[dt][jq] = mfma16(vf, pb[jq], o[dt][jq]);
-        }
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16(frag_tr(Vs, 32 * kb, 32 * kb + 16, dt * 16, lane), pb, o[dt]);
     }
-#pragma unroll
-    for (int jq = 0; jq < QT; ++jq) {
-        if (qtok[jq] < 0) continue;
+    if (qtok >= 0) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             bf16x4 ov;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (bf16)(o[dt][jq][r] * inv[jq]);
-            *(bf16x4*)(p.out + (long)qtok[jq] * C + hoff + dt * 16 + 4 * fg) = ov;
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16)(o[dt][r] * inv);
+            *(bf16x4*)(p.out + (long)qtok * C + hoff + dt * 16 + 4 * fg) = ov;
         }
     }
 }
@@ -225,27 +242,28 @@ __global__ __launch_bounds__(64 * WCfg<NTILES>::WAVES) void wattn_fwd_kernel(WAt
 // backward
 // ------------------------------------------------------------------------------------------------
 template <int NTILES>
-__global__ __launch_bounds__(64 * WCfg<NTILES>::WAVES) void wattn_bwd_kernel(WAttn p) {
+__global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p) {
     using Cf = WCfg<NTILES>;
-    constexpr int WAVES = Cf::WAVES, QT = Cf::QT, NP = Cf::NP, NKB = Cf::NKB, KP = Cf::KP, NK2 = NKB * 32;
-    constexpr int NTH = 64 * WAVES;
-    constexpr int OFF_TOK = 3 * 32 * KP * 2;
+    constexpr int NTH = Cf::NTH, NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
+    constexpr int OFF_TOK = 4 * NK2 * 64;
     constexpr int OFF_LSE = OFF_TOK + NK2 * 4;
     constexpr int OFF_DEL = OFF_LSE + NK2 * 4;
     constexpr int OFF_YX = OFF_DEL + NK2 * 4;
     constexpr int OFF_RID = OFF_YX + NK2 * 2;
     constexpr int OFF_TAB = (OFF_RID + NK2 + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16* Kt = (bf16*)smem;
-    bf16* Qt = Kt + 32 * KP;
-    bf16* dOt = Qt + 32 * KP;
+    unsigned char* Qs = smem;
+    unsigned char* Ks = smem + NK2 * 64;
+    unsigned char* Vs = smem + 2 * NK2 * 64;
+    unsigned char* dOs = smem + 3 * NK2 * 64;
     int* tokoff = (int*)(smem + OFF_TOK);
     float* lse = (float*)(smem + OFF_LSE);
     float* delta = (float*)(smem + OFF_DEL);
     unsigned short* yx = (unsigned short*)(smem + OFF_YX);
     unsigned char* rid = smem + OFF_RID;
-    float* tab = (float*)(smem + OFF_TAB);
+    float* tab = (float*)(smem + OFF_TAB);          // 4 replicas (one per lane group fg): conflict-free ds_add
     const int T1 = 2 * p.ws - 1, TT = T1 * T1;
+    float* padacc = tab + 4 * TT;                   // [3][32] q|k|v bias gradient from padding slots
 
     int win, head;
     decode_block(p, win, head);
@@ -253,262 +271,210 @@ __global__ __launch_bounds__(64 * WCfg<NTILES>::WAVES) void wattn_bwd_kernel(WAt
     const int b = win / p.nWin, wrem = win - b * p.nWin;
     const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-    const int C = p.C, C3 = 3 * p.C, hoff = head * 32;
+    const int C = p.C, hoff = head * 32;
+    const long C3 = 3 * (long)p.C;
 
-    window_slots<NP>(p, b, wi, wj, tokoff, rid, yx, NTH);
-    for (int t = NP + threadIdx.x; t < NK2; t += NTH) { tokoff[t] = -2; rid[t] = 0; yx[t] = 0; }
-    for (int t = threadIdx.x; t < TT; t += NTH) tab[t] = 0.f;
-    for (int t = threadIdx.x; t < NK2; t += NTH) { lse[t] = 0.f; delta[t] = 0.f; }
+    float4 bq[NTILES];       // bias_q row segment of this lane's query (phase A), later bias_k of its key (phase B)
+    {
+        const float* brow0 = p.bias_q + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
+#pragma unroll
+        for (int kt = 0; kt < NTILES; ++kt) bq[kt] = *(const float4*)(brow0 + kt * 16);
+    }
+    window_slots<NK2>(p, b, wi, wj, tokoff, rid, yx, NTH);
+    for (int t = threadIdx.x; t < 4 * TT + 96; t += NTH) tab[t] = 0.f;
     __syncthreads();
-    stage_transposed<KP, NK2>(Kt, p.qkv, C3, p.qkv_bias, false, C + hoff, tokoff, NTH);
-    stage_transposed<KP, NK2>(Qt, p.qkv, C3, p.qkv_bias, false, hoff, tokoff, NTH);
-    stage_transposed<KP, NK2>(dOt, p.d_out, C, nullptr, true, hoff, tokoff, NTH);
+    {
+        unsigned char* const img[4] = {Qs, Ks, Vs, dOs};
+        const bf16* const base[4] = {p.qkv + hoff, p.qkv + C + hoff, p.qkv + 2 * C + hoff, p.d_out + hoff};
+        const long stride[4] = {C3, C3, C3, (long)C};
+        const bf16* const pad[4] = {p.qkv_bias + hoff, p.qkv_bias + C + hoff, p.qkv_bias + 2 * C + hoff, nullptr};
+        stage_images<4, NK2, NTH>(img, base, stride, pad, tokoff);
+    }
     __syncthreads();
 
-    auto rowp = [&](int tok) -> const bf16* { return tok >= 0 ? p.qkv + (long)tok * C3 : p.qkv_bias; };
-    auto load_do = [&](int tok) -> bf16x8 {
-        return tok >= 0 ? *(const bf16x8*)(p.d_out + (long)tok * C + hoff + 8 * fg) : zero8();
-    };
+    const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
+    const float sc = p.scale * LOG2E;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // ---------------- phase A: key-major scores, dQ, softmax statistics, dTable ----------------
+    // ---------------- phase A: this wave's 16 queries x all keys (key-major S^T): statistics, dTable, dQ ----------------
     {
-        bf16x8 qf[QT], dof[QT];
-        int qtok[QT];
-        float dl[QT];
+        const int qt = wave, qi = qt * 16 + fr;
+        const int qtok = tokoff[qi];
+        const bf16x8 qf = frag_rows(Qs, qt * 16, fr, fg);
+        const bf16x8 dof = frag_rows(dOs, qt * 16, fr, fg);
+        float dl = 0.f;                               // delta[q] = sum_d dO[q][d] * O[q][d]
+        if (qtok >= 0) {
+            const bf16x8 ov = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
 #pragma unroll
-        for (int jq = 0; jq < QT; ++jq) {
-            const int qt = wave * QT + jq;
-            qtok[jq] = qt < NTILES ? tokoff[qt * 16 + fr] : -2;
-            qf[jq] = *(const bf16x8*)(rowp(qtok[jq]) + hoff + 8 * fg);
-            dof[jq] = load_do(qtok[jq]);
-            // delta[q] = sum_d dO[q][d] * O[q][d]
-            float part = 0.f;
-            if (qtok[jq] >= 0) {
-                const bf16x8 ov = *(const bf16x8*)(p.o_saved + (long)qtok[jq] * C + hoff + 8 * fg);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) part += (float)ov[j] * (float)dof[jq][j];
-            }
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            dl[jq] = part;
+            for (int j = 0; j < 8; ++j) dl += (float)ov[j] * (float)dof[j];
         }
-        f32x4 s[NTILES][QT];
+        dl += __shfl_xor(dl, 16);
+        dl += __shfl_xor(dl, 32);
+        f32x4 s[NTILES];
+        const int ridq = rid[qi];
+        float mx = -1e30f;
 #pragma unroll
         for (int kt = 0; kt < NTILES; ++kt) {
-            const bf16x8 kf = *(const bf16x8*)(rowp(tokoff[kt * 16 + fr]) + C + hoff + 8 * fg);
-#pragma unroll
-            for (int jq = 0; jq < QT; ++jq) s[kt][jq] = mfma16(kf, qf[jq], zero4);
-        }
-#pragma unroll
-        for (int jq = 0; jq < QT; ++jq) {
-            const int qt = wave * QT + jq;
-            const int qi = (qt < NTILES ? qt : 0) * 16 + fr;
-            const int ridq = rid[qi];
-            const float* brow = p.bias_q + ((long)head * NP + qi) * NP;
-            float mx = -1e30f;
-#pragma unroll
-            for (int kt = 0; kt < NTILES; ++kt) {
-                const float4 bb = *(const float4*)(brow + kt * 16 + 4 * fg);
+            s[kt] = mfma16(frag_rows(Ks, kt * 16, fr, fg), qf, zero4);
+            const float4 bb = bq[kt];
+            s[kt][0] = s[kt][0] * sc + bb.x; s[kt][1] = s[kt][1] * sc + bb.y;
+            s[kt][2] = s[kt][2] * sc + bb.z; s[kt][3] = s[kt][3] * sc + bb.w;
+            if (masked) {
                 const unsigned rk = *(const unsigned*)(rid + kt * 16 + 4 * fg);
-                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kt][jq][r] * p.scale + bv[r];
-                    if (p.shift > 0 && (int)((rk >> (8 * r)) & 0xffu) != ridq) v -= 100.0f;
-                    s[kt][jq][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if ((int)((rk >> (8 * r)) & 0xffu) != ridq) s[kt][r] -= 100.0f * LOG2E;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NTILES; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[kt][jq][r] - mx);
-                    s[kt][jq][r] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            if (qt < NTILES && fg == 0) { lse[qi] = mx + __logf(sum); delta[qi] = dl[jq]; }
-            // dS^T = P * (dP^T - delta), dP^T[key][q] = V[key] . dO[q]
-            const int qcode = yx[qi];
-            const int qy = qcode >> 8, qx = qcode & 0xff;
-            const bool qreal = qt < NTILES && qi < p.N;
-#pragma unroll
-            for (int kt = 0; kt < NTILES; ++kt) {
-                const bf16x8 vf = *(const bf16x8*)(rowp(tokoff[kt * 16 + fr]) + 2 * C + hoff + 8 * fg);
-                const f32x4 dp = mfma16(vf, dof[jq], zero4);
-                const uint2 kc = *(const uint2*)(yx + kt * 16 + 4 * fg);
-                const unsigned kcs[4] = {kc.x & 0xffffu, kc.x >> 16, kc.y & 0xffffu, kc.y >> 16};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ds = s[kt][jq][r] * inv * (dp[r] - dl[jq]);
-                    s[kt][jq][r] = ds;
-                    const int key = kt * 16 + 4 * fg + r;
-                    if (qreal && key < p.N) {
-                        const int ky = kcs[r] >> 8, kx = kcs[r] & 0xff;
-                        atomicAdd(&tab[(qy - ky + p.ws - 1) * T1 + (qx - kx + p.ws - 1)], ds);
-                    }
-                }
-            }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);     // bound the loads hoisted ahead (register pressure)
         }
-        // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
-        f32x4 dq[2][QT];
+        {   // bias_q is consumed: start fetching the key-major bias of phase B (this wave's key tile) into the same registers
+            const float* bcol0 = p.bias_k + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int qt2 = 0; qt2 < NTILES; ++qt2) bq[qt2] = *(const float4*)(bcol0 + qt2 * 16);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
 #pragma unroll
-            for (int jq = 0; jq < QT; ++jq) dq[dt][jq] = zero4;
+        for (int kt = 0; kt < NTILES; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        if (fg == 0) { lse[qi] = mx + log2f(sum); delta[qi] = dl; }     // log2-domain log-sum-exp
+        __builtin_amdgcn_sched_barrier(0);
+        const int qcode = yx[qi];
+        const int qy = qcode >> 8, qx = qcode & 0xff;
+        const bool qreal = qi < p.N;
+#pragma unroll
+        for (int kt = 0; kt < NTILES; ++kt) {
+            const f32x4 dp = mfma16(frag_rows(Vs, kt * 16, fr, fg), dof, zero4);     // dP^T[key][q] = V[key] . dO[q]
+            const uint2 kc = *(const uint2*)(yx + kt * 16 + 4 * fg);
+            const unsigned kcs[4] = {kc.x & 0xffffu, kc.x >> 16, kc.y & 0xffffu, kc.y >> 16};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ds = s[kt][r] * inv * (dp[r] - dl);
+                s[kt][r] = ds;
+                const int key = kt * 16 + 4 * fg + r;
+                if (qreal && key < p.N) {
+                    const int ky = kcs[r] >> 8, kx = kcs[r] & 0xff;
+                    atomicAdd(&tab[fg * TT + (qy - ky + p.ws - 1) * T1 + (qx - kx + p.ws - 1)], ds);
+                }
+            }
+            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 dq[2] = {zero4, zero4};                  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            bf16x8 pb[QT];
+            bf16x8 pb;
 #pragma unroll
-            for (int jq = 0; jq < QT; ++jq)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pb[jq][r] = (bf16)s[2 * kb][jq][r];
-                    pb[jq][4 + r] = (2 * kb + 1 < NTILES) ? (bf16)s[(2 * kb + 1 < NTILES) ? 2 * kb + 1 : 0][jq][r] : (bf16)0.f;
-                }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16* krow = Kt + (dt * 16 + fr) * KP + 32 * kb + 4 * fg;
-                const bf16x4 lo = *(const bf16x4*)krow, hi = *(const bf16x4*)(krow + 16);
-                bf16x8 kf;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { kf[r] = lo[r]; kf[4 + r] = hi[r]; }
-#pragma unroll
-                for (int jq = 0; jq < QT; ++jq) dq[dt][jq] = mfma16(kf, pb[jq], dq[dt][jq]);
+            for (int r = 0; r < 4; ++r) {
+                pb[r] = (bf16)s[2 * kb][r];
+                pb[4 + r] = (2 * kb + 1 < NTILES) ? (bf16)s[(2 * kb + 1 < NTILES) ? 2 * kb + 1 : 0][r] : (bf16)0.f;
             }
-        }
 #pragma unroll
-        for (int jq = 0; jq < QT; ++jq) {
-            const int qt = wave * QT + jq;
-            if (qt >= NTILES || qtok[jq] == -2) continue;
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma16(frag_tr(Ks, 32 * kb, 32 * kb + 16, dt * 16, lane), pb, dq[dt]);
+        }
+        if (qtok != -2) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int col = hoff + dt * 16 + 4 * fg;
-                if (qtok[jq] >= 0) {
+                if (qtok >= 0) {
                     bf16x4 ov;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = (bf16)(dq[dt][jq][r] * p.scale);
-                    *(bf16x4*)(p.dqkv + (long)qtok[jq] * C3 + col) = ov;
+                    for (int r = 0; r < 4; ++r) ov[r] = (bf16)(dq[dt][r] * p.scale);
+                    *(bf16x4*)(p.dqkv + (long)qtok * C3 + col) = ov;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(p.dbias_pad + col + r, dq[dt][jq][r] * p.scale);
+                    for (int r = 0; r < 4; ++r) atomicAdd(padacc + dt * 16 + 4 * fg + r, dq[dt][r] * p.scale);
                 }
             }
         }
     }
     __syncthreads();   // lse / delta / tab complete
 
-    // ---------------- phase B: query-major scores, dK and dV of this wave's key tiles ----------------
+    // ---------------- phase B: this wave's 16 keys x all queries (query-major S): dK, dV ----------------
     {
-        bf16x8 kfB[QT], vfB[QT];
-        int ktok[QT];
+        const int kt = wave, ki = kt * 16 + fr;
+        const int ktok = tokoff[ki];
+        const bf16x8 kfB = frag_rows(Ks, kt * 16, fr, fg);
+        const bf16x8 vfB = frag_rows(Vs, kt * 16, fr, fg);
+        const int ridk = rid[ki];
+        f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
 #pragma unroll
-        for (int jk = 0; jk < QT; ++jk) {
-            const int kt = wave * QT + jk;
-            ktok[jk] = kt < NTILES ? tokoff[kt * 16 + fr] : -2;
-            kfB[jk] = *(const bf16x8*)(rowp(ktok[jk]) + C + hoff + 8 * fg);
-            vfB[jk] = *(const bf16x8*)(rowp(ktok[jk]) + 2 * C + hoff + 8 * fg);
-        }
-        f32x4 dk[2][QT], dv[2][QT];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int jk = 0; jk < QT; ++jk) { dk[dt][jk] = zero4; dv[dt][jk] = zero4; }
-#pragma unroll 1
         for (int qb = 0; qb < NKB; ++qb) {
-            f32x4 pt[2][QT], dst[2][QT];
+            f32x4 pt[2], dst[2];
 #pragma unroll
-            for (int qi2 = 0; qi2 < 2; ++qi2) {
-                const int qt = 2 * qb + qi2;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int qt = 2 * qb + h2;
                 if (qt < NTILES) {
-                    const int qtk = tokoff[qt * 16 + fr];
-                    const bf16x8 qa = *(const bf16x8*)(rowp(qtk) + hoff + 8 * fg);
-                    const bf16x8 da = load_do(qtk);
+                    const f32x4 sv = mfma16(frag_rows(Qs, qt * 16, fr, fg), kfB, zero4);    // S[q = 4fg+r][key = fr]
+                    const f32x4 dp = mfma16(frag_rows(dOs, qt * 16, fr, fg), vfB, zero4);
+                    const float4 bb = bq[qt < NTILES ? qt : 0];
                     const float4 l4 = *(const float4*)(lse + qt * 16 + 4 * fg);
                     const float4 d4 = *(const float4*)(delta + qt * 16 + 4 * fg);
-                    const unsigned rq = *(const unsigned*)(rid + qt * 16 + 4 * fg);
-                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                    for (int jk = 0; jk < QT; ++jk) {
-                        const int kt = wave * QT + jk;
-                        const int ki = (kt < NTILES ? kt : 0) * 16 + fr;
-                        const f32x4 sv = mfma16(qa, kfB[jk], zero4);     // S[q = 4fg+r][key = fr]
-                        const f32x4 dp = mfma16(da, vfB[jk], zero4);
-                        const float4 bb = *(const float4*)(p.bias_k + ((long)head * NP + ki) * NP + qt * 16 + 4 * fg);
-                        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-                        const int ridk = rid[ki];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = sv[r] * p.scale + bv[r];
-                            if (p.shift > 0 && (int)((rq >> (8 * r)) & 0xffu) != ridk) v -= 100.0f;
-                            const float pr = (kt < NTILES) ? __expf(v - lv[r]) : 0.f;
-                            pt[qi2][jk][r] = pr;
-                            dst[qi2][jk][r] = pr * (dp[r] - dv4[r]);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int jk = 0; jk < QT; ++jk) { pt[qi2][jk] = zero4; dst[qi2][jk] = zero4; }
-                }
-            }
-            // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16* orow = dOt + (dt * 16 + fr) * KP + 32 * qb + 4 * fg;
-                const bf16* qrow = Qt + (dt * 16 + fr) * KP + 32 * qb + 4 * fg;
-                const bf16x4 olo = *(const bf16x4*)orow, ohi = *(const bf16x4*)(orow + 16);
-                const bf16x4 qlo = *(const bf16x4*)qrow, qhi = *(const bf16x4*)(qrow + 16);
-                bf16x8 of, qf2;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { of[r] = olo[r]; of[4 + r] = ohi[r]; qf2[r] = qlo[r]; qf2[4 + r] = qhi[r]; }
-#pragma unroll
-                for (int jk = 0; jk < QT; ++jk) {
-                    bf16x8 pb, db;
+                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w};
+                    const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+                    unsigned rq = 0;
+                    if (masked) rq = *(const unsigned*)(rid + qt * 16 + 4 * fg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pb[r] = (bf16)pt[0][jk][r]; pb[4 + r] = (bf16)pt[1][jk][r];
-                        db[r] = (bf16)dst[0][jk][r]; db[4 + r] = (bf16)dst[1][jk][r];
+                        float v = sv[r] * sc + bv[r];
+                        if (masked && (int)((rq >> (8 * r)) & 0xffu) != ridk) v -= 100.0f * LOG2E;
+                        const float pr = exp2f(v - lv[r]);
+                        pt[h2][r] = pr;
+                        dst[h2][r] = pr * (dp[r] - dv4[r]);
                     }
-                    dv[dt][jk] = mfma16(of, pb, dv[dt][jk]);
-                    dk[dt][jk] = mfma16(qf2, db, dk[dt][jk]);
+                } else {
+                    pt[h2] = zero4; dst[h2] = zero4;
                 }
             }
-        }
+            bf16x8 pb, db;
 #pragma unroll
-        for (int jk = 0; jk < QT; ++jk) {
-            const int kt = wave * QT + jk;
-            if (kt >= NTILES || ktok[jk] == -2) continue;
+            for (int r = 0; r < 4; ++r) {
+                pb[r] = (bf16)pt[0][r]; pb[4 + r] = (bf16)pt[1][r];
+                db[r] = (bf16)dst[0][r]; db[4 + r] = (bf16)dst[1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = mfma16(frag_tr(dOs, 32 * qb, 32 * qb + 16, dt * 16, lane), pb, dv[dt]);   // dV^T += dO^T P
+                dk[dt] = mfma16(frag_tr(Qs, 32 * qb, 32 * qb + 16, dt * 16, lane), db, dk[dt]);    // dK^T += Q^T dS
+            }
+        }
+        if (ktok != -2) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int col = hoff + dt * 16 + 4 * fg;
-                if (ktok[jk] >= 0) {
+                if (ktok >= 0) {
                     bf16x4 kv, vv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { kv[r] = (bf16)(dk[dt][jk][r] * p.scale); vv[r] = (bf16)dv[dt][jk][r]; }
-                    *(bf16x4*)(p.dqkv + (long)ktok[jk] * C3 + C + col) = kv;
-                    *(bf16x4*)(p.dqkv + (long)ktok[jk] * C3 + 2 * C + col) = vv;
+                    for (int r = 0; r < 4; ++r) { kv[r] = (bf16)(dk[dt][r] * p.scale); vv[r] = (bf16)dv[dt][r]; }
+                    *(bf16x4*)(p.dqkv + (long)ktok * C3 + C + col) = kv;
+                    *(bf16x4*)(p.dqkv + (long)ktok * C3 + 2 * C + col) = vv;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        atomicAdd(p.dbias_pad + C + col + r, dk[dt][jk][r] * p.scale);
-                        atomicAdd(p.dbias_pad + 2 * C + col + r, dv[dt][jk][r]);
+                        atomicAdd(padacc + 32 + dt * 16 + 4 * fg + r, dk[dt][r] * p.scale);
+                        atomicAdd(padacc + 64 + dt * 16 + 4 * fg + r, dv[dt][r]);
                     }
                 }
             }
         }
     }
-    // relative-position table gradient of this (window, head): one contiguous burst
-    for (int t = threadIdx.x; t < TT; t += NTH) atomicAdd(p.dtab + (long)head * TT + t, tab[t]);
+    __syncthreads();
+    // this (window, head)'s partial gradients: one contiguous row of the workspace
+    float* wsrow = p.dtab_ws + ((long)win * p.nH + head) * (TT + 96);
+    for (int t = threadIdx.x; t < TT; t += NTH) wsrow[t] = tab[t] + tab[TT + t] + tab[2 * TT + t] + tab[3 * TT + t];
+    for (int t = threadIdx.x; t < 96; t += NTH) wsrow[TT + t] = padacc[t];
 }
 
-// expanded relative-position bias: table ((2ws-1)^2, nH) fp32 -> bias_q [h][q][key], bias_k [h][key][q]
+// expanded relative-position bias: table ((2ws-1)^2, nH) fp32 -> log2(e)-scaled bias_q [h][q][key], bias_k [h][key][q]
 __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ bias_q, float* __restrict__ bias_k,
                                      int nH, int ws, int NP) {
     const int N = ws * ws, T1 = 2 * ws - 1;
@@ -519,7 +485,7 @@ __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __r
         if (key >= N) v = -30000.0f;
         else if (q < N) {
             const int qy = q / ws, qx = q % ws, ky = key / ws, kx = key % ws;
-            v = table[((qy - ky + ws - 1) * T1 + (qx - kx + ws - 1)) * nH + h];
+            v = LOG2E * table[((qy - ky + ws - 1) * T1 + (qx - kx + ws - 1)) * nH + h];
         }
         bias_q[i] = v;
         bias_k[((long)h * NP + key) * NP + q] = v;
@@ -545,32 +511,29 @@ static int fill_params(WAttn& p, const void* qkv, const void* qkv_bias, const fl
     if (!(qkv && qkv_bias && bias_q && B > 0 && H > 0 && W > 0 && nH > 0 && C == nH * 32)) return UENC_EINVAL;
     if (!(ws >= 1 && ws <= 12 && shift >= 0 && shift < ws)) return UENC_EINVAL;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)qkv_bias & 15)) return UENC_EINVAL;
+    if ((long)B * H * W * 3 * C >= (1L << 31)) return UENC_EINVAL;     // 32-bit token offsets
     p.qkv = (const bf16*)qkv; p.qkv_bias = (const bf16*)qkv_bias; p.bias_q = bias_q; p.bias_k = bias_k;
     p.B = B; p.H = H; p.W = W; p.C = C; p.nH = nH; p.ws = ws; p.shift = shift;
     p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
     p.nWw = p.Wp / ws; p.nWin = (p.Hp / ws) * p.nWw; p.nWinTotal = B * p.nWin; p.N = ws * ws;
     p.scale = scale;
-    p.out = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab = nullptr; p.dbias_pad = nullptr;
+    p.out = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab_ws = nullptr;
     return UENC_OK;
 }
 
 template <int NT>
 static void launch_fwd(const WAttn& p, hipStream_t stream) {
     const unsigned grid = (unsigned)((p.nWinTotal + 7) / 8 * 8 * p.nH);
-    hipLaunchKernelGGL(wattn_fwd_kernel<NT>, dim3(grid), dim3(64 * WCfg<NT>::WAVES), 0, stream, p);
+    hipLaunchKernelGGL(wattn_fwd_kernel<NT>, dim3(grid), dim3(64 * NT), 0, stream, p);
 }
 template <int NT>
 static int launch_bwd(const WAttn& p, hipStream_t stream) {
     using Cf = WCfg<NT>;
-    constexpr int NK2 = Cf::NKB * 32;
+    constexpr int NK2 = Cf::NK2;
     const int T1 = 2 * p.ws - 1;
-    const size_t shm = (size_t)((3 * 32 * Cf::KP * 2 + NK2 * 4 * 3 + NK2 * 2 + NK2 + 15) / 16 * 16) + (size_t)T1 * T1 * 4;
+    const size_t shm = (size_t)((4 * NK2 * 64 + NK2 * 4 * 3 + NK2 * 2 + NK2 + 15) / 16 * 16) + (size_t)(4 * T1 * T1 + 96) * 4;
     const unsigned grid = (unsigned)((p.nWinTotal + 7) / 8 * 8 * p.nH);
-    if (shm > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * Cf::WAVES), shm, stream, p);
+    hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), shm, stream, p);
     return UENC_OK;
 }
 
@@ -601,14 +564,22 @@ extern "C" int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const
     UENC_LAUNCH_RET();
 }
 
+// dtab_ws: (B * nWin * nH, (2ws-1)^2 + 96) fp32 scratch, fully overwritten: row (win * nH + head) holds that
+// workgroup's partial gradient of the relative-position table followed by the [3][32] (q|k|v) slice of the
+// qkv-bias gradient that reaches head `head` through padding slots (the caller sums over windows).
+extern "C" long uenc_window_attn_bwd_ws_rows(int B, int H, int W, int nH, int ws) {
+    const long Hp = (H + ws - 1) / ws, Wp = (W + ws - 1) / ws;
+    return (long)B * Hp * Wp * nH;
+}
+
 extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                                    const void* o_saved, const void* d_out, void* dqkv, float* dtab, float* dbias_pad, int B,
-                                    int H, int W, int C, int nH, int ws, int shift, float scale, hipStream_t stream) {
+                                    const void* o_saved, const void* d_out, void* dqkv, float* dtab_ws,
+                                    int B, int H, int W, int C, int nH, int ws, int shift, float scale, hipStream_t stream) {
     WAttn p;
     int rc = fill_params(p, qkv, qkv_bias, bias_q, bias_k, B, H, W, C, nH, ws, shift, scale);
     if (rc != UENC_OK) return rc;
-    UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dtab && dbias_pad);
-    p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab = dtab; p.dbias_pad = dbias_pad;
+    UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dtab_ws);
+    p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab_ws = dtab_ws;
 #define CALL(NT) { rc = launch_bwd<NT>(p, stream); if (rc != UENC_OK) return rc; }
     WATTN_DISPATCH(wattn_ntiles(ws), CALL)
 #undef CALL

@@ -153,11 +153,16 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
     assert d_out.dtype == torch.bfloat16 and d_out.is_contiguous() and d_out.shape == (B, H, W, C)
     assert o_saved.dtype == torch.bfloat16 and o_saved.is_contiguous()
     dqkv = torch.empty_like(qkv)
-    dtab = torch.zeros((nH, (2 * ws - 1) ** 2), dtype=torch.float32, device=qkv.device)
-    dpad = torch.zeros((C3,), dtype=torch.float32, device=qkv.device)
+    TT = (2 * ws - 1) ** 2
+    rows = lib.uenc_window_attn_bwd_ws_rows(B, H, W, nH, ws)
+    # per-(window, head) partials: [table gradient (TT) | q,k,v bias gradient through padding slots (3 x 32)]
+    wsbuf = torch.empty((rows, TT + 96), dtype=torch.float32, device=qkv.device)
     check(lib.uenc_window_attn_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), bias_k.data_ptr(),
-                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), dtab.data_ptr(), dpad.data_ptr(),
+                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(),
                                    B, H, W, C, nH, ws, shift, float(scale), stream_ptr()), "window_attn_bwd")
+    part = wsbuf.view(rows // nH, nH, TT + 96).sum(0)                    # (nH, TT + 96)
+    dtab = part[:, :TT]
+    dpad = part[:, TT:].reshape(nH, 3, 32).permute(1, 0, 2).reshape(3 * C)   # [q|k|v][head][32]
     return dqkv, dtab, dpad
 
 
