@@ -241,3 +241,27 @@ def test_gemm_tn_f32_dy(K):
     dw = torch.zeros(64, 40, device="cuda")
     K.gemm_tn(dy, x, dw, None)
     _close(dw, dy.to(torch.bfloat16).float().t() @ x.to(torch.bfloat16).float(), 5e-2, 2e-3)
+
+
+@pytest.mark.parametrize("M,N,K_", [(4096, 2560, 128), (5000, 2312, 192), (16384, 768, 768), (3000, 3584, 64 * 5)])
+def test_gemm_nt_large_tile_path(K, M, N, K_):
+    """Shapes that take the 256x256 LDS-DMA kernel (bf16 A, K % 64 == 0, >= 160 tiles), incl. ragged M / N and epilogues."""
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias = _r(N, seed=3)
+    pre = a.float() @ w.float().t() + bias
+    _close(K.gemm_nt(a, w, bias=bias, out_dtype=torch.float32), pre, 2e-3, 2e-3)
+    _close(K.gemm_nt(a, w, bias=bias), pre, 2e-2, 1e-2)
+    pre_out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    _close(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_GELU, aux_out=pre_out), torch.nn.functional.gelu(pre), 2e-2, 1e-2)
+    _close(pre_out, pre, 2e-2, 1e-2)
+    res = _r(M, N, seed=4)
+    res2 = res.clone()
+    K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res2, out=res2)
+    _close(res2, pre + res, 2e-3, 2e-3)
+    saved = _r(M, N, seed=5, dtype=torch.bfloat16)
+    _close(K.gemm_nt(a, w, epilogue=K.EPI_MUL_DRELU, aux=saved), (pre - bias) * (saved.float() > 0), 3e-2, 2e-2)
+    # exact check with an asymmetric integer operand (catches fragment / swizzle mistakes)
+    ai = (torch.arange(M * K_, dtype=torch.float32).reshape(M, K_) % 7 - 3).to(torch.bfloat16).cuda()
+    wi = (torch.arange(N * K_, dtype=torch.float32).reshape(N, K_) % 5 - 2).to(torch.bfloat16).cuda()
+    _close(K.gemm_nt(ai, wi, out_dtype=torch.float32), ai.float() @ wi.float().t(), 0, 0)

@@ -18,6 +18,7 @@
 // and conflict-free ds_write_b128 staging.
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -37,13 +38,32 @@ struct GemmNT {
     int tiles_m, tiles_n;
     int klen;      // K elements handled by one split (multiple of BK); == K rounded up when splitk == 1
     int atomic;    // fp32 atomicAdd into C (split-K or accumulate)
+    int variant;   // debug A/B switch
     float alpha;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// load 8 consecutive k of one row as bf16x8 (zero outside)
-__device__ __forceinline__ u32x4 load_row8(const void* base, int is_f32, long ld, int row, int nrows, int k, int kend) {
+// Load 8 consecutive k of one row as bf16x8, zero outside [0, nrows) x [0, kend).  Branch-free: the address is
+// clamped into the matrix and the result masked, so a thread's loads issue back to back.
+template <bool F32>
+__device__ __forceinline__ u32x4 load_row8(const void* base, long ld, int row, int nrows, int k, int kend, int K) {
+    const bool ok = (row < nrows) && (k < kend);
+    const int rc = min(row, nrows - 1), kc = min(k, K - 8);
+    u32x4 v;
+    if (F32) {
+        const float* p = (const float*)base + (long)rc * ld + kc;
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        const bf16x8 r = cvt8(a, b);
+        v = *(const u32x4*)&r;
+    } else {
+        v = *(const u32x4*)((const bf16*)base + (long)rc * ld + kc);
+    }
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    return ok ? v : z;
+}
+
+__device__ __forceinline__ u32x4 load_row8_br(const void* base, int is_f32, long ld, int row, int nrows, int k, int kend) {
     u32x4 z = {0u, 0u, 0u, 0u};
     if (row >= nrows || k >= kend) return z;
     if (is_f32) {
@@ -77,10 +97,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
     u32x4 ra[4], rw[4];
     auto gload = [&](int kt) {
         const int k = kbeg + kt * BK + schunk * 8;
+        if (p.variant & 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = load_row8(p.A, p.a_f32, p.lda, m0 + srow + 32 * i, p.M, k, kend);
-            rw[i] = load_row8(p.W, 0, p.ldw, n0 + srow + 32 * i, p.N, k, kend);
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = load_row8_br(p.A, p.a_f32, p.lda, m0 + srow + 32 * i, p.M, k, kend);
+                rw[i] = load_row8_br(p.W, 0, p.ldw, n0 + srow + 32 * i, p.N, k, kend);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = load_row8<false>(p.W, p.ldw, n0 + srow + 32 * i, p.N, k, kend, p.K);
+        if (p.a_f32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = load_row8<true>(p.A, p.lda, m0 + srow + 32 * i, p.M, k, kend, p.K);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = load_row8<false>(p.A, p.lda, m0 + srow + 32 * i, p.M, k, kend, p.K);
         }
     };
     auto lstore = [&](int buf) {
@@ -118,65 +150,276 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
         __syncthreads();
     }
 
-    // epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + 0..3]
+    // ---- epilogue ----
+    // split-K / accumulate: fp32 atomics straight from the accumulators (lane holds C[m = ..+fr][n = ..+4fg+0..3])
     const bool lead = (blockIdx.y == 0);
+    if (p.atomic) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= p.M) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + fr;
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + 4 * fg;
-            if (n >= p.N) continue;
-            float v[4];
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + i * 16 + 4 * fg;
+                if (n >= p.N) continue;
+                float* c = (float*)p.C + (long)m * p.ldc + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (p.bias != nullptr && lead) {
-                const float4 b = *(const float4*)(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r];
+                    if (p.bias != nullptr && lead) v += p.bias[n + r];
+                    atomicAdd(c + r, v * p.alpha);
+                }
             }
+        }
+        return;
+    }
+    // Coalesced path: the fp32 tile goes through LDS (two 64-row halves, rows padded to 132 floats so the
+    // accumulator writes are bank-conflict free), then every thread owns 8 consecutive columns of a row: bias /
+    // residual / saved activations are read and the result written as full 128-byte-per-16-lanes row segments.
+    float* T = (float*)smem;
+    constexpr int LDT = 132;
+    const int erow = t >> 4, ecol = (t & 15) * 8;
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wm == h) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;     // alpha * (A W^T + bias): per-sample DropPath scale
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(f32x4*)(T + (j * 16 + fr) * LDT + wn * 64 + i * 16 + 4 * fg) = acc[i][j];
+        }
+        __syncthreads();
+        const int n = n0 + ecol;
+        if (n >= p.N) continue;
+        const bool full8 = (n + 8 <= p.N);                 // N % 4 == 0: either 8 or 4 valid columns
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+            const float4 b0 = *(const float4*)(p.bias + n);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+            if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int rl = ps * 16 + erow;
+            const int m = m0 + h * 64 + rl;
+            if (m >= p.M) continue;
+            const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * p.alpha; v[4 + r] = (a1[r] + bv[4 + r]) * p.alpha; }
             if (EPI == EPI_GELU) {
                 if (p.aux_out != nullptr) {
-                    bf16x4 pre;
+                    bf16x8 pre;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pre[r] = (bf16)v[r];
-                    *(bf16x4*)(p.aux_out + (long)m * p.ldaux_out + n) = pre;
+                    for (int r = 0; r < 8; ++r) pre[r] = (bf16)v[r];
+                    bf16* dst = p.aux_out + (long)m * p.ldaux_out + n;
+                    if (full8) *(bf16x8*)dst = pre;
+                    else { bf16x4 q4; q4[0] = pre[0]; q4[1] = pre[1]; q4[2] = pre[2]; q4[3] = pre[3]; *(bf16x4*)dst = q4; }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
             } else if (EPI == EPI_RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
             } else if (EPI == EPI_RESIDUAL) {
-                const float4 rr = *(const float4*)((const float*)p.aux + (long)m * p.ldaux + n);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            } else if (EPI == EPI_MUL_DGELU) {
-                const bf16x4 pre = *(const bf16x4*)((const bf16*)p.aux + (long)m * p.ldaux + n);
+                const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                const float4 r0 = *(const float4*)rp;
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
+            } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
+                const bf16* ap = (const bf16*)p.aux + (long)m * p.ldaux + n;
+                bf16x8 sv;
+                if (full8) sv = *(const bf16x8*)ap;
+                else {
+                    const bf16x4 q4 = *(const bf16x4*)ap;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= dgelu_f((float)pre[r]);
-            } else if (EPI == EPI_MUL_DRELU) {
-                const bf16x4 post = *(const bf16x4*)((const bf16*)p.aux + (long)m * p.ldaux + n);
+                    for (int r = 0; r < 4; ++r) { sv[r] = q4[r]; sv[4 + r] = (bf16)0.f; }
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ((float)post[r] > 0.f) ? v[r] : 0.f;
+                for (int r = 0; r < 8; ++r)
+                    v[r] = (EPI == EPI_MUL_DGELU) ? v[r] * dgelu_f((float)sv[r]) : (((float)sv[r] > 0.f) ? v[r] : 0.f);
             }
             if (OUT_F32) {
                 float* c = (float*)p.C + (long)m * p.ldc + n;
-                if (p.atomic) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
-                } else {
-                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
             } else {
-                bf16x4 o;
+                bf16x8 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-                *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+                for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                bf16* c = (bf16*)p.C + (long)m * p.ldc + n;
+                if (full8) *(bf16x8*)c = o;
+                else { bf16x4 q4; q4[0] = o[0]; q4[1] = o[1]; q4[2] = o[2]; q4[3] = o[3]; *(bf16x4*)c = q4; }
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Large-tile variant for the GEMMs that carry most of the FLOPs (stage 3 / 4 of the backbone,
+// K % 64 == 0, bf16 A): 256 x 256 x 64 tile, 8 waves (2 x 4), each wave 128(m) x 64(n) = 8 x 4
+// MFMA tiles (128 accumulator VGPRs), one workgroup per CU.  Operands go global -> LDS directly
+// (global_load_lds_dwordx4: no staging registers, 8 instructions per thread per k-tile), two 64 KB
+// stages: the DMA of k-tile t+1 is issued before the 64 MFMAs per wave of k-tile t and waited for
+// after them, one barrier per k-tile.  LDS-DMA writes lane-linearly (wave base + lane * 16 B), so
+// the XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied to the
+// per-lane SOURCE address (cdna_hip_programming.md rule 21).
+// ---------------------------------------------------------------------------------------------
+#define BM2 256
+#define BN2 256
+#define T2 512
+
+template <int EPI, int OUT_F32>
+__global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (A 32 KB + W 32 KB)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    const int m0 = mt * BM2, n0 = nt * BN2;
+    const int nkt = p.K / BK;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // DMA geometry: instruction q of a thread fills LDS chunk index L = q * 512 + t  (row L >> 3, slot L & 7)
+    const bf16* asrc[4];
+    const bf16* wsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 64 + (t >> 3), slot = t & 7;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        asrc[q] = (const bf16*)p.A + (long)min(m0 + row, p.M - 1) * p.lda + chunk * 8;
+        wsrc[q] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + chunk * 8;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue = [&](int kt, int stage) {
+        unsigned char* As = smem + stage * 65536;
+        unsigned char* Ws = As + 32768;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds(asrc[q] + kt * BK, (lds_void*)(As + (q * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(wsrc[q] + kt * BK, (lds_void*)(Ws + (q * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    issue(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();     // waits for this wave's DMA (vmcnt 0), then everyone: tile kt landed, stage (kt+1)&1 is free
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        const unsigned char* As = smem + (kt & 1) * 65536;
+        const unsigned char* Ws = As + 32768;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[4], xf[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(Ws + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(As + lds_off(wm * 128 + j * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+        }
+    }
+
+    // epilogue: four passes of 64 rows through a padded fp32 LDS tile [64][260]; then 8 columns per thread
+    float* T = (float*)smem;
+    constexpr int LDT = 260;
+    const int erow = t >> 5, ecol = (t & 31) * 8;
+    const int n = n0 + ecol;
+    const bool ncol_ok = n < p.N;
+    const bool full8 = (n + 8 <= p.N);
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && ncol_ok) {
+        const float4 b0 = *(const float4*)(p.bias + n);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
+    }
+    for (int ps = 0; ps < 4; ++ps) {
+        __syncthreads();
+        if (wm == (ps >> 1)) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = (ps & 1) * 4 + jj;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(f32x4*)(T + (jj * 16 + fr) * LDT + wn * 64 + i * 16 + 4 * fg) = acc[i][j];
+            }
+        }
+        __syncthreads();
+        if (!ncol_ok) continue;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 16 + erow;
+            const int m = m0 + ps * 64 + rl;
+            if (m >= p.M) continue;
+            const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * p.alpha; v[4 + r] = (a1[r] + bv[4 + r]) * p.alpha; }
+            if (EPI == EPI_GELU) {
+                if (p.aux_out != nullptr) {
+                    bf16x8 pre;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pre[r] = (bf16)v[r];
+                    bf16* dst = p.aux_out + (long)m * p.ldaux_out + n;
+                    if (full8) *(bf16x8*)dst = pre;
+                    else { bf16x4 q4; q4[0] = pre[0]; q4[1] = pre[1]; q4[2] = pre[2]; q4[3] = pre[3]; *(bf16x4*)dst = q4; }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+            } else if (EPI == EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (EPI == EPI_RESIDUAL) {
+                const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                const float4 r0 = *(const float4*)rp;
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
+            } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
+                const bf16* ap = (const bf16*)p.aux + (long)m * p.ldaux + n;
+                bf16x8 sv;
+                if (full8) sv = *(const bf16x8*)ap;
+                else {
+                    const bf16x4 q4 = *(const bf16x4*)ap;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sv[r] = q4[r]; sv[4 + r] = (bf16)0.f; }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    v[r] = (EPI == EPI_MUL_DGELU) ? v[r] * dgelu_f((float)sv[r]) : (((float)sv[r] > 0.f) ? v[r] : 0.f);
+            }
+            if (OUT_F32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                bf16* c = (bf16*)p.C + (long)m * p.ldc + n;
+                if (full8) *(bf16x8*)c = o;
+                else { bf16x4 q4; q4[0] = o[0]; q4[1] = o[1]; q4[2] = o[2]; q4[3] = o[3]; *(bf16x4*)c = q4; }
+            }
+        }
+    }
+}
+
+template <int EPI, int OUT_F32>
+static int launch_nt256(GemmNT& p, hipStream_t stream) {
+    p.tiles_m = (p.M + BM2 - 1) / BM2; p.tiles_n = (p.N + BN2 - 1) / BN2;
+    static bool attr_set = false;      // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n), dim3(T2), 131072, stream, p);
+    return UENC_OK;
 }
 
 extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
@@ -193,6 +436,7 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
     if (splitk < 1) splitk = 1;
     if (splitk > 1 || accumulate) UENC_CHECK_ARG(c_dtype == UENC_F32 && epilogue == EPI_NONE);
     GemmNT p;
+    { const char* e = getenv("UENC_GEMM_VARIANT"); p.variant = e ? atoi(e) : 0; }
     p.A = A; p.a_f32 = (a_dtype == UENC_F32); p.lda = lda;
     p.W = (const bf16*)W; p.ldw = ldw;
     p.C = C; p.ldc = ldc; p.bias = bias; p.aux = aux; p.ldaux = ldaux;
@@ -208,6 +452,31 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
     dim3 grid(p.tiles_m * p.tiles_n, splitk), block(GEMM_THREADS);
     const bool prof = uenc_prof_on();
     if (prof) uenc_prof_begin(UENC_PROF_GEMM_NT, 2.0 * M * (double)N * K, stream);
+    // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
+    const bool big = !p.atomic && a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) &&
+                     ((long)((M + 255) / 256) * ((N + 255) / 256) >= 160) && N >= 256;
+    if (big) {
+        int rc = UENC_EINVAL;
+#define LAUNCH2(E, F) rc = launch_nt256<E, F>(p, stream)
+        if (c_dtype == UENC_F32) {
+            if (epilogue == EPI_NONE) LAUNCH2(EPI_NONE, 1);
+            else if (epilogue == EPI_RESIDUAL) LAUNCH2(EPI_RESIDUAL, 1);
+            else if (epilogue == EPI_RELU) LAUNCH2(EPI_RELU, 1);
+        } else {
+            switch (epilogue) {
+                case EPI_NONE: LAUNCH2(EPI_NONE, 0); break;
+                case EPI_GELU: LAUNCH2(EPI_GELU, 0); break;
+                case EPI_RELU: LAUNCH2(EPI_RELU, 0); break;
+                case EPI_MUL_DGELU: LAUNCH2(EPI_MUL_DGELU, 0); break;
+                case EPI_MUL_DRELU: LAUNCH2(EPI_MUL_DRELU, 0); break;
+                default: break;
+            }
+        }
+#undef LAUNCH2
+        if (rc != UENC_OK) return rc;
+        if (prof) uenc_prof_end(stream);
+        UENC_LAUNCH_RET();
+    }
 #define LAUNCH(E, F) hipLaunchKernelGGL((gemm_nt_kernel<E, F>), grid, block, 0, stream, p)
     if (c_dtype == UENC_F32) {
         if (epilogue == EPI_NONE) LAUNCH(EPI_NONE, 1);
@@ -249,13 +518,13 @@ struct GemmTN {
 };
 
 __device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
-    // in[r] = row r (8 bf16 = 4 dwords), out[c] = column c as 8 bf16 (rows 0..7)
+    // in[r] = row r (8 bf16 = 4 dwords), out[c] = column c as 8 bf16 (rows 0..7): one v_perm_b32 per output dword
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const unsigned lo = in[2 * w][c >> 1], hi = in[2 * w + 1][c >> 1];
-            out[c][w] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            out[c][w] = __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
         }
     }
 }
@@ -289,14 +558,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
     u32x4 rin[8];
     auto gload = [&](int it) {
         const int mrow = mbeg + it * BK + mb * 8;
-        if (role == 0) {
-            const int col = n0 + cb * 8;
+        const void* src = role == 0 ? p.dY : p.X;
+        const long ld = role == 0 ? p.ldy : p.ldx;
+        const int ncols = role == 0 ? p.N : p.K;
+        const int col = (role == 0 ? n0 : k0) + cb * 8;
+        if (role == 0 ? p.dy_f32 : p.x_f32) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) rin[r] = load_row8(p.dY, p.dy_f32, p.ldy, mrow + r, mend, col, p.N);
+            for (int r = 0; r < 8; ++r) rin[r] = load_row8<true>(src, ld, mrow + r, mend, col, ncols, ncols);
         } else {
-            const int col = k0 + cb * 8;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) rin[r] = load_row8(p.X, p.x_f32, p.ldx, mrow + r, mend, col, p.K);
+            for (int r = 0; r < 8; ++r) rin[r] = load_row8<false>(src, ld, mrow + r, mend, col, ncols, ncols);
         }
     };
     auto lstore = [&](int buf) {
