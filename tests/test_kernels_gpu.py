@@ -265,3 +265,26 @@ def test_gemm_nt_large_tile_path(K, M, N, K_):
     ai = (torch.arange(M * K_, dtype=torch.float32).reshape(M, K_) % 7 - 3).to(torch.bfloat16).cuda()
     wi = (torch.arange(N * K_, dtype=torch.float32).reshape(N, K_) % 5 - 2).to(torch.bfloat16).cuda()
     _close(K.gemm_nt(ai, wi, out_dtype=torch.float32), ai.float() @ wi.float().t(), 0, 0)
+
+
+@pytest.mark.parametrize("M,N,K_", [(4096, 512, 256), (2048, 576, 192), (8192, 768, 3072), (6400, 264, 200)])
+def test_gemm_tn_large_tile_path(K, M, N, K_, monkeypatch):
+    """wgrad shapes through the 256x256 LDS-DMA + transposed-read kernel (forced: production gates it to >= 20
+    output tiles), incl. ragged N / K tiles and db."""
+    monkeypatch.setenv("UENC_GEMM_VARIANT", "8")
+    dy = _r(M, N, seed=1, dtype=torch.bfloat16)
+    x = _r(M, K_, seed=2, dtype=torch.bfloat16)
+    dw = _r(N, K_, seed=3)
+    db = _r(N, seed=4)
+    want_w = dw + dy.float().t() @ x.float()
+    want_b = db + dy.float().sum(0)
+    K.gemm_tn(dy, x, dw, db)
+    tol = 4e-3 * (M ** 0.5)
+    _close(dw, want_w, tol, 2e-3)
+    _close(db, want_b, tol, 2e-3)
+    # exact: small integers, asymmetric
+    dyi = (torch.arange(M * N, dtype=torch.float32).reshape(M, N) % 5 - 2).to(torch.bfloat16).cuda()
+    xi = (torch.arange(M * K_, dtype=torch.float32).reshape(M, K_) % 3 - 1).to(torch.bfloat16).cuda()
+    dwi = torch.zeros(N, K_, device="cuda")
+    K.gemm_tn(dyi, xi, dwi, None, splitm=1)
+    _close(dwi, dyi.float().t() @ xi.float(), 0, 0)

@@ -23,3 +23,15 @@ for M, N, Kd in shapes:
             os.environ["UENC_GEMM_VARIANT"] = v
             res[v].append(fl / timeit(lambda: K.gemm_nt(a, w, out=out)))
     print(f"{M}x{N}x{Kd}: " + "  ".join(f"{v}: med {sorted(r)[2]:.0f} max {max(r):.0f}" for v, r in res.items()))
+
+print("--- wgrad (TN): variant 0 = large-tile, 4 = 128x128 register-transposing kernel")
+for M, N, Kd in [(16384, 3072, 768), (16384, 768, 3072), (16384, 768, 768), (16384, 2304, 768), (65536, 1536, 384), (262144, 576, 192), (4096, 6144, 1536)]:
+    dy = torch.randn(M, N, device="cuda").to(torch.bfloat16); x = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
+    dw = torch.zeros(N, Kd, device="cuda"); db = torch.zeros(N, device="cuda"); fl = 2.0 * M * N * Kd / 1e9
+    res = {"0": [], "4": [], "torch": []}
+    for rnd in range(5):
+        for v in ("0", "4"):
+            os.environ["UENC_GEMM_VARIANT"] = v
+            res[v].append(fl / timeit(lambda: K.gemm_tn(dy, x, dw, db)))
+        res["torch"].append(fl / timeit(lambda: torch.matmul(dy.t(), x)))
+    print(f"{M}x{N}x{Kd}: " + "  ".join(f"{v}: med {sorted(r)[2]:.0f} max {max(r):.0f}" for v, r in res.items()))

@@ -47,13 +47,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_f(float x) {  // exact erf form (torch.nn.GELU default)
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+// erf-form GELU (torch.nn.GELU default).  erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the
+// bf16 rounding of the stored result): one v_rcp, one v_exp and a 5-term Horner chain instead of libm's erff,
+// which cost more than the GEMM main loop of the fc1 layers when evaluated 128 times per thread in the epilogue.
+__device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& gauss) {   // for z = |x| / sqrt(2)
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    gauss = __expf(-z * z);                                                        // = exp(-x^2 / 2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    erf_abs = 1.0f - poly * gauss;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e, g;
+    erf_parts(x, e, g);
+    return 0.5f * x * (1.0f + copysignf(e, x));
 }
 __device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e, g;
+    erf_parts(x, e, g);
+    return 0.5f * (1.0f + copysignf(e, x)) + x * g * 0.39894228040143268f;
 }
 
 __device__ __forceinline__ bf16x8 cvt8(const float4& a, const float4& b) {

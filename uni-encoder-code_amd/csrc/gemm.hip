@@ -648,6 +648,146 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Large-tile wgrad: dW[n][k] += sum_m dY[m][n] X[m][k] with a 256(k) x 256(n) output tile, 8 waves.
+// Both operands are token-major, i.e. the contraction index m is the ROW of both images, so neither
+// can be read as a row fragment.  They are brought in untransposed by LDS-DMA (64 tokens x 256
+// columns x 2 operands = 64 KB per stage, two stages) and every MFMA fragment is fetched with the
+// hardware transposing read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group): no register
+// transposes, no staging VGPRs.  512-byte rows; 32-byte pieces are XOR-permuted by
+// (row & 3) | ((row >> 3) & 1) << 2 on the DMA source side so that the 8 row-pieces a 32-lane half
+// reads fall into 8 different 32-byte bank groups.  The token range is split over blockIdx.y; the
+// fp32 tile is added to dW through LDS in 256-byte contiguous atomic bursts.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_off(int row, int col) {        // byte offset of element (row, col) in a [64][256] bf16 image
+    const int piece = (col >> 4) ^ ((row & 3) | (((row >> 3) & 1) << 2));      // 32-byte piece index (16 per row), low 3 bits permuted
+    return row * 512 + piece * 32 + (col & 15) * 2;
+}
+
+// fragment with the contraction index on rows: lane (i = lane & 15 -> column c0 + i; k-slots j' = rows r0 + 8*(lane>>4) + j')
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* img, int r0, int c0, int lane) {
+    const int fg = lane >> 4, i = lane & 15, q4 = i >> 2, p4 = i & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int ra = r0 + 8 * fg + q4, col = c0 + 4 * p4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + tn_off(ra, col)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + tn_off(ra + 4, col)));
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+    return r;
+}
+
+__global__ __launch_bounds__(T2) void gemm_tn256_kernel(GemmTN p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (dY 32 KB + X 32 KB)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave >> 2, wn = wave & 3;            // wave tile: 128 (k) x 64 (n)
+    const int tile = blockIdx.x;
+    const int ntile = tile / p.tiles_k, ktile = tile - ntile * p.tiles_k;
+    const int n0 = ntile * 256, k0 = ktile * 256;
+    const int mbeg = blockIdx.y * p.mlen;
+    const int mend = min(p.M, mbeg + p.mlen);
+    const int nst = (mend - mbeg) / 64;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // DMA: instruction q fills LDS 16-byte slot L = q * 512 + t of an image: row L >> 5, position P = L & 31
+    const bf16* ysrc[4];
+    const bf16* xsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 16 + (t >> 5), P = t & 31;
+        const int piece = (P >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2));
+        const int col = piece * 16 + (P & 1) * 8;
+        ysrc[q] = (const bf16*)p.dY + (long)(mbeg + row) * p.ldy + min(n0 + col, p.N - 8);
+        xsrc[q] = (const bf16*)p.X + (long)(mbeg + row) * p.ldx + min(k0 + col, p.K - 8);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue = [&](int st, int stage) {
+        unsigned char* Ys = smem + stage * 65536;
+        unsigned char* Xs = Ys + 32768;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds(ysrc[q] + (long)st * 64 * p.ldy, (lds_void*)(Ys + (q * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xsrc[q] + (long)st * 64 * p.ldx, (lds_void*)(Xs + (q * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // bias gradient (k-tile 0 only): thread owns 8 columns (one 16-byte chunk) and 4 of the 64 rows of each stage
+    const bool do_db = (p.db != nullptr) && (ktile == 0);
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) issue(0, 0);
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();
+        if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
+        const unsigned char* Ys = smem + (st & 1) * 65536;
+        const unsigned char* Xs = Ys + 32768;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 kf[8], nf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nf[j] = tn_frag(Ys, ks * 32, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = tn_frag(Xs, ks * 32, wk * 128 + i * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(kf[i], nf[j], acc[i][j]);
+        }
+        if (do_db) {
+            const int c8 = (t & 31) * 8, rg = t >> 5;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const bf16x8 v = *(const bf16x8*)(Ys + tn_off(rg + 16 * rr, c8));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bsum[c] += (float)v[c];
+            }
+        }
+    }
+
+    float* T = (float*)smem;
+    constexpr int LDT = 260;
+    if (do_db) {            // reduce the 16 row-groups through LDS, then one atomic per column
+        __syncthreads();
+        const int c8 = (t & 31) * 8, rg = t >> 5;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) T[rg * 256 + c8 + c] = bsum[c];
+        __syncthreads();
+        if (t < 256) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += T[g * 256 + t];
+            if (n0 + t < p.N) atomicAdd(p.db + n0 + t, v);
+        }
+    }
+    // acc[i][j][r] = dW[n = n0 + wn*64 + j*16 + fr][k = k0 + wk*128 + i*16 + 4*fg + r]; four passes of 64 n-rows
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int ps = 0; ps < 4; ++ps) {
+        __syncthreads();
+        if (wn == ps) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *(f32x4*)(T + (j * 16 + fr) * LDT + wk * 128 + i * 16 + 4 * fg) = acc[i][j];
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += 8) {
+            const int n = n0 + ps * 64 + row;
+            if (n >= p.N) break;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + lane + 64 * q;
+                if (k < p.K) atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+            }
+        }
+    }
+}
+
 extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
                             float* db, int M, int N, int K, int splitm, hipStream_t stream) {
     UENC_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0);
@@ -658,6 +798,31 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     GemmTN p;
     p.dY = dY; p.dy_f32 = (dy_dtype == UENC_F32); p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
     p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
+    // large-tile path: bf16 operands, whole 64-token stages, output wide enough for 256 x 256 tiles
+    { const char* e = getenv("UENC_GEMM_VARIANT"); const int variant = e ? atoi(e) : 0;
+      // (needs >= 20 output tiles: with the split of the token range capped at 8, fewer tiles cannot fill the chip)
+      if (dy_dtype == UENC_BF16 && x_dtype == UENC_BF16 && M % 64 == 0 && M >= 2048 && !(variant & 4) &&
+          ((variant & 8) || (long)((N + 255) / 256) * ((K + 255) / 256) >= 20)) {
+        p.tiles_n = (N + 255) / 256; p.tiles_k = (K + 255) / 256;
+        const int tiles = p.tiles_n * p.tiles_k, stages = M / 64;
+        int sp = splitm > 0 ? splitm : (256 + tiles - 1) / tiles;
+        if (sp > 8) sp = 8;                       // every split adds a 256 KB atomic burst per tile
+        if (sp > stages / 8) sp = stages / 8 > 0 ? stages / 8 : 1;
+        p.mlen = ((stages + sp - 1) / sp) * 64;
+        sp = (M + p.mlen - 1) / p.mlen;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            if (e2 != hipSuccess) return (int)e2;
+            attr_set = true;
+        }
+        const bool prof2 = uenc_prof_on();
+        if (prof2) uenc_prof_begin(UENC_PROF_GEMM_TN, 2.0 * M * (double)N * K, stream);
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles, sp), dim3(T2), 131072, stream, p);
+        if (prof2) uenc_prof_end(stream);
+        UENC_LAUNCH_RET();
+      }
+    }
     p.tiles_n = (N + BN - 1) / BN; p.tiles_k = (K + BM - 1) / BM;
     const int mt = (M + BK - 1) / BK;
     if (splitm < 1) {

@@ -336,19 +336,21 @@ class SwinBlockFn(torch.autograd.Function):
         if not d2.is_contiguous():
             d2 = d2.contiguous()
         train = wqkv.requires_grad
-        # MLP branch
-        dh = K.gemm_nt(d2, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)              # (M, 4C) d(pre-GELU)
+        # MLP branch (bf16 copy of the incoming stream gradient: the dgrad / wgrad GEMMs read bf16 operands)
+        d2h = K.cast_bf16(d2)
+        dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)             # (M, 4C) d(pre-GELU)
         if train:
-            K.gemm_tn(d2, h, grad_buf(w2), grad_buf(bb2))
+            K.gemm_tn(d2h, h, grad_buf(w2), grad_buf(bb2))
         dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))                                              # (M, C)
         if train:
             K.gemm_tn(dh, xn2, grad_buf(w1), grad_buf(bb1))
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None)
         # attention branch
-        dattn = K.gemm_nt(dx1, CACHE.mat_t(wproj))                                         # (M, C) bf16
+        dx1h = K.cast_bf16(dx1)
+        dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))                                        # (M, C) bf16
         if train:
-            K.gemm_tn(dx1, attn.view(M, C), grad_buf(wproj), grad_buf(bproj))
+            K.gemm_tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj))
         dqkv, dtab, dpad = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn,
                                              dattn.view(B, H, W, C), ws, shift, scale)
         dqkv2 = dqkv.view(M, 3 * C)
