@@ -267,11 +267,12 @@ def test_gemm_nt_large_tile_path(K, M, N, K_):
     _close(K.gemm_nt(ai, wi, out_dtype=torch.float32), ai.float() @ wi.float().t(), 0, 0)
 
 
-@pytest.mark.parametrize("M,N,K_", [(4096, 512, 256), (2048, 576, 192), (8192, 768, 3072), (6400, 264, 200)])
-def test_gemm_tn_large_tile_path(K, M, N, K_, monkeypatch):
-    """wgrad shapes through the 256x256 LDS-DMA + transposed-read kernel (forced: production gates it to >= 20
-    output tiles), incl. ragged N / K tiles and db."""
-    monkeypatch.setenv("UENC_GEMM_VARIANT", "8")
+@pytest.mark.parametrize("variant", ["0", "8"])
+@pytest.mark.parametrize("M,N,K_", [(4096, 512, 256), (2048, 576, 192), (8192, 768, 3072), (6400, 264, 200), (2048, 96, 48)])
+def test_gemm_tn_large_tile_path(K, M, N, K_, variant, monkeypatch):
+    """wgrad shapes through the LDS-DMA + transposed-read kernels: production dispatch (128x128 tiles for small
+    outputs, 256x256 from 20 tiles up) and the 256x256 kernel forced; ragged N / K tiles and db."""
+    monkeypatch.setenv("UENC_GEMM_VARIANT", variant)
     dy = _r(M, N, seed=1, dtype=torch.bfloat16)
     x = _r(M, K_, seed=2, dtype=torch.bfloat16)
     dw = _r(N, K_, seed=3)

@@ -63,18 +63,6 @@ __device__ __forceinline__ u32x4 load_row8(const void* base, long ld, int row, i
     return ok ? v : z;
 }
 
-__device__ __forceinline__ u32x4 load_row8_br(const void* base, int is_f32, long ld, int row, int nrows, int k, int kend) {
-    u32x4 z = {0u, 0u, 0u, 0u};
-    if (row >= nrows || k >= kend) return z;
-    if (is_f32) {
-        const float* p = (const float*)base + (long)row * ld + k;
-        float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-        bf16x8 r = cvt8(a, b);
-        return *(u32x4*)&r;
-    }
-    return *(const u32x4*)((const bf16*)base + (long)row * ld + k);
-}
-
 template <int EPI, int OUT_F32>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
@@ -97,14 +85,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
     u32x4 ra[4], rw[4];
     auto gload = [&](int kt) {
         const int k = kbeg + kt * BK + schunk * 8;
-        if (p.variant & 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = load_row8_br(p.A, p.a_f32, p.lda, m0 + srow + 32 * i, p.M, k, kend);
-                rw[i] = load_row8_br(p.W, 0, p.ldw, n0 + srow + 32 * i, p.N, k, kend);
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) rw[i] = load_row8<false>(p.W, p.ldw, n0 + srow + 32 * i, p.N, k, kend, p.K);
         if (p.a_f32) {
@@ -179,6 +159,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
     float* T = (float*)smem;
     constexpr int LDT = 132;
     const int erow = t >> 4, ecol = (t & 15) * 8;
+#pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
         if (wm == h) {
@@ -340,7 +321,8 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
         bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
         if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
     }
-    for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {      // unrolled: acc[][] must keep compile-time indices (else it lives in scratch)
         __syncthreads();
         if (wm == (ps >> 1)) {
 #pragma unroll
@@ -626,6 +608,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
     // two passes of 64 n-rows through a padded fp32 LDS tile [64][132]
     float* T = (float*)smem;
     const int LDT = 132;
+#pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
         if (wn == h) {
@@ -660,47 +643,56 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
 // reads fall into 8 different 32-byte bank groups.  The token range is split over blockIdx.y; the
 // fp32 tile is added to dW through LDS in 256-byte contiguous atomic bursts.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tn_off(int row, int col) {        // byte offset of element (row, col) in a [64][256] bf16 image
-    const int piece = (col >> 4) ^ ((row & 3) | (((row >> 3) & 1) << 2));      // 32-byte piece index (16 per row), low 3 bits permuted
-    return row * 512 + piece * 32 + (col & 15) * 2;
+template <int COLS>
+__device__ __forceinline__ int tn_off(int row, int col) {        // byte offset of element (row, col) in a [64][COLS] bf16 image
+    const int piece = (col >> 4) ^ ((row & 3) | (((row >> 3) & 1) << 2));      // 32-byte piece index, low 3 bits permuted
+    return row * (COLS * 2) + piece * 32 + (col & 15) * 2;
 }
 
 // fragment with the contraction index on rows: lane (i = lane & 15 -> column c0 + i; k-slots j' = rows r0 + 8*(lane>>4) + j')
+template <int COLS>
 __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* img, int r0, int c0, int lane) {
     const int fg = lane >> 4, i = lane & 15, q4 = i >> 2, p4 = i & 3;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const int ra = r0 + 8 * fg + q4, col = c0 + 4 * p4;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + tn_off(ra, col)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + tn_off(ra + 4, col)));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + tn_off<COLS>(ra, col)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + tn_off<COLS>(ra + 4, col)));
     bf16x8 r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
     return r;
 }
 
-__global__ __launch_bounds__(T2) void gemm_tn256_kernel(GemmTN p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (dY 32 KB + X 32 KB)
+// TILE = 256: 8 waves (2 x 4), wave tile 128(k) x 64(n), 128 KB LDS, one workgroup per CU.
+// TILE = 128: 4 waves (2 x 2), wave tile  64(k) x 64(n),  64 KB LDS, two workgroups per CU (small N x K outputs, long token ranges).
+template <int TILE>
+__global__ __launch_bounds__(TILE * 2) void gemm_tnbig_kernel(GemmTN p) {
+    constexpr int NTHR = TILE * 2, NWN = TILE / 64, WKT = (TILE == 256 ? 8 : 4);     // waves along n; 16-wide k tiles per wave
+    constexpr int IMG = 64 * TILE * 2;                                                   // bytes of one operand image
+    constexpr int RPI = NTHR * 16 / (TILE * 2);                                          // rows filled per DMA instruction
+    constexpr int CPR = TILE / 8;                                                        // 16-byte slots per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                 // 2 stages x (dY + X)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wk = wave >> 2, wn = wave & 3;            // wave tile: 128 (k) x 64 (n)
+    const int wk = wave / NWN, wn = wave % NWN;
     const int tile = blockIdx.x;
     const int ntile = tile / p.tiles_k, ktile = tile - ntile * p.tiles_k;
-    const int n0 = ntile * 256, k0 = ktile * 256;
+    const int n0 = ntile * TILE, k0 = ktile * TILE;
     const int mbeg = blockIdx.y * p.mlen;
     const int mend = min(p.M, mbeg + p.mlen);
     const int nst = (mend - mbeg) / 64;
 
-    f32x4 acc[8][4];
+    f32x4 acc[WKT][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < WKT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // DMA: instruction q fills LDS 16-byte slot L = q * 512 + t of an image: row L >> 5, position P = L & 31
+    // DMA: instruction q fills LDS 16-byte slot L = q * NTHR + t of an image: row L / CPR, position P = L % CPR
     const bf16* ysrc[4];
     const bf16* xsrc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int row = q * 16 + (t >> 5), P = t & 31;
+        const int row = q * RPI + t / CPR, P = t % CPR;
         const int piece = (P >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2));
         const int col = piece * 16 + (P & 1) * 8;
         ysrc[q] = (const bf16*)p.dY + (long)(mbeg + row) * p.ldy + min(n0 + col, p.N - 8);
@@ -708,12 +700,12 @@ __global__ __launch_bounds__(T2) void gemm_tn256_kernel(GemmTN p) {
     }
     typedef __attribute__((address_space(3))) void lds_void;
     auto issue = [&](int st, int stage) {
-        unsigned char* Ys = smem + stage * 65536;
-        unsigned char* Xs = Ys + 32768;
+        unsigned char* Ys = smem + stage * (2 * IMG);
+        unsigned char* Xs = Ys + IMG;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_global_load_lds(ysrc[q] + (long)st * 64 * p.ldy, (lds_void*)(Ys + (q * 512 + wave * 64) * 16), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(xsrc[q] + (long)st * 64 * p.ldx, (lds_void*)(Xs + (q * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(ysrc[q] + (long)st * 64 * p.ldy, (lds_void*)(Ys + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xsrc[q] + (long)st * 64 * p.ldx, (lds_void*)(Xs + (q * NTHR + wave * 64) * 16), 16, 0, 0);
         }
     };
 
@@ -725,25 +717,25 @@ __global__ __launch_bounds__(T2) void gemm_tn256_kernel(GemmTN p) {
     for (int st = 0; st < nst; ++st) {
         __syncthreads();
         if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
-        const unsigned char* Ys = smem + (st & 1) * 65536;
-        const unsigned char* Xs = Ys + 32768;
+        const unsigned char* Ys = smem + (st & 1) * (2 * IMG);
+        const unsigned char* Xs = Ys + IMG;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 kf[8], nf[4];
+            bf16x8 kf[WKT], nf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) nf[j] = tn_frag(Ys, ks * 32, wn * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j) nf[j] = tn_frag<TILE>(Ys, ks * 32, wn * 64 + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kf[i] = tn_frag(Xs, ks * 32, wk * 128 + i * 16, lane);
+            for (int i = 0; i < WKT; ++i) kf[i] = tn_frag<TILE>(Xs, ks * 32, wk * (WKT * 16) + i * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < WKT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(kf[i], nf[j], acc[i][j]);
         }
         if (do_db) {
-            const int c8 = (t & 31) * 8, rg = t >> 5;
+            const int c8 = (t % CPR) * 8, rg = t / CPR;       // 16 row groups
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const bf16x8 v = *(const bf16x8*)(Ys + tn_off(rg + 16 * rr, c8));
+                const bf16x8 v = *(const bf16x8*)(Ys + tn_off<TILE>(rg + 16 * rr, c8));
 #pragma unroll
                 for (int c = 0; c < 8; ++c) bsum[c] += (float)v[c];
             }
@@ -751,41 +743,66 @@ __global__ __launch_bounds__(T2) void gemm_tn256_kernel(GemmTN p) {
     }
 
     float* T = (float*)smem;
-    constexpr int LDT = 260;
+    constexpr int LDT = TILE + 4;
     if (do_db) {            // reduce the 16 row-groups through LDS, then one atomic per column
         __syncthreads();
-        const int c8 = (t & 31) * 8, rg = t >> 5;
+        const int c8 = (t % CPR) * 8, rg = t / CPR;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) T[rg * 256 + c8 + c] = bsum[c];
+        for (int c = 0; c < 8; ++c) T[rg * TILE + c8 + c] = bsum[c];
         __syncthreads();
-        if (t < 256) {
+        if (t < TILE) {
             float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) v += T[g * 256 + t];
+            for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
             if (n0 + t < p.N) atomicAdd(p.db + n0 + t, v);
         }
     }
-    // acc[i][j][r] = dW[n = n0 + wn*64 + j*16 + fr][k = k0 + wk*128 + i*16 + 4*fg + r]; four passes of 64 n-rows
+    // acc[i][j][r] = dW[n = n0 + wn*64 + j*16 + fr][k = k0 + wk*WKT*16 + i*16 + 4*fg + r]; passes of 64 n-rows
     const int fr = lane & 15, fg = lane >> 4;
-    for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+    for (int ps = 0; ps < NWN; ++ps) {
         __syncthreads();
         if (wn == ps) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) *(f32x4*)(T + (j * 16 + fr) * LDT + wk * 128 + i * 16 + 4 * fg) = acc[i][j];
+                for (int i = 0; i < WKT; ++i) *(f32x4*)(T + (j * 16 + fr) * LDT + wk * (WKT * 16) + i * 16 + 4 * fg) = acc[i][j];
         }
         __syncthreads();
-        for (int row = wave; row < 64; row += 8) {
+        for (int row = wave; row < 64; row += NTHR / 64) {
             const int n = n0 + ps * 64 + row;
             if (n >= p.N) break;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < TILE / 64; ++q) {
                 const int k = k0 + lane + 64 * q;
                 if (k < p.K) atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
             }
         }
     }
+}
+
+template <int TILE>
+static int launch_tnbig(GemmTN& p, int M, int N, int K, int splitm, int max_split, hipStream_t stream) {
+    p.tiles_n = (N + TILE - 1) / TILE; p.tiles_k = (K + TILE - 1) / TILE;
+    const int tiles = p.tiles_n * p.tiles_k, stages = M / 64;
+    const int per_cu = TILE == 256 ? 1 : 2;
+    int sp = splitm > 0 ? splitm : (256 * per_cu + tiles - 1) / tiles;
+    if (sp > max_split) sp = max_split;
+    if (sp > stages / 8) sp = stages / 8 > 0 ? stages / 8 : 1;
+    p.mlen = ((stages + sp - 1) / sp) * 64;
+    sp = (M + p.mlen - 1) / p.mlen;
+    constexpr int SHM = 4 * 64 * TILE * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tnbig_kernel<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM);
+        if (e2 != hipSuccess) return (int)e2;
+        attr_set = true;
+    }
+    const bool prof2 = uenc_prof_on();
+    if (prof2) uenc_prof_begin(UENC_PROF_GEMM_TN, 2.0 * M * (double)N * K, stream);
+    hipLaunchKernelGGL(gemm_tnbig_kernel<TILE>, dim3(tiles, sp), dim3(TILE * 2), SHM, stream, p);
+    if (prof2) uenc_prof_end(stream);
+    return UENC_OK;
 }
 
 extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
@@ -798,28 +815,15 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     GemmTN p;
     p.dY = dY; p.dy_f32 = (dy_dtype == UENC_F32); p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
     p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
-    // large-tile path: bf16 operands, whole 64-token stages, output wide enough for 256 x 256 tiles
+    // LDS-DMA paths: bf16 operands, whole 64-token stages.  256x256 tiles when the output has >= 20 of them (every split
+    // of the token range costs a 256 KB atomic burst per tile, so splits are capped at 8); else 128x128 tiles, whose
+    // outputs are small enough to split the token range much further.
     { const char* e = getenv("UENC_GEMM_VARIANT"); const int variant = e ? atoi(e) : 0;
-      // (needs >= 20 output tiles: with the split of the token range capped at 8, fewer tiles cannot fill the chip)
-      if (dy_dtype == UENC_BF16 && x_dtype == UENC_BF16 && M % 64 == 0 && M >= 2048 && !(variant & 4) &&
-          ((variant & 8) || (long)((N + 255) / 256) * ((K + 255) / 256) >= 20)) {
-        p.tiles_n = (N + 255) / 256; p.tiles_k = (K + 255) / 256;
-        const int tiles = p.tiles_n * p.tiles_k, stages = M / 64;
-        int sp = splitm > 0 ? splitm : (256 + tiles - 1) / tiles;
-        if (sp > 8) sp = 8;                       // every split adds a 256 KB atomic burst per tile
-        if (sp > stages / 8) sp = stages / 8 > 0 ? stages / 8 : 1;
-        p.mlen = ((stages + sp - 1) / sp) * 64;
-        sp = (M + p.mlen - 1) / p.mlen;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            if (e2 != hipSuccess) return (int)e2;
-            attr_set = true;
-        }
-        const bool prof2 = uenc_prof_on();
-        if (prof2) uenc_prof_begin(UENC_PROF_GEMM_TN, 2.0 * M * (double)N * K, stream);
-        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles, sp), dim3(T2), 131072, stream, p);
-        if (prof2) uenc_prof_end(stream);
+      if (dy_dtype == UENC_BF16 && x_dtype == UENC_BF16 && M % 64 == 0 && M >= 2048 && !(variant & 4)) {
+        int rc;
+        if ((variant & 8) || (long)((N + 255) / 256) * ((K + 255) / 256) >= 20) rc = launch_tnbig<256>(p, M, N, K, splitm, 8, stream);
+        else rc = launch_tnbig<128>(p, M, N, K, splitm, 64, stream);
+        if (rc != UENC_OK) return rc;
         UENC_LAUNCH_RET();
       }
     }
