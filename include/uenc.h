@@ -108,6 +108,24 @@ int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int64_t* shapes
                            float* grad_loc, float* grad_attn, int B, int S, int M, int D, int L, int Lq, int P,
                            void* stream);
 
+/* ---- decoder multi-head attention core (head_dim 32) --------------------------------------------------------
+ * softmax(scale * q k^T [blocked where mask != 0]) v for every nn.MultiheadAttention of the transformer decoder
+ * (transformer_decoder/oneformer_transformer_decoder.py:63-67,122-127 with the mask of :504-511; transformer.py:268-297).
+ * q (B,Lq,*) / k, v (B,S,*) bf16 with heads interleaved in the row (head h at columns 32h..32h+31); *_bs / *_rs are
+ * batch / row strides in elements (multiples of 8).  mask (B,Lq,mask_rs) bytes, shared by all heads, mask_rs a multiple
+ * of 4 and >= S, or NULL.  out (B,Lq,*) bf16; lse (B,H,Lq) fp32 log2-domain log-sum-exp (needed by the backward).
+ * workspace: uenc_mha_fwd_workspace_floats(...) floats (split-KV partials); NULL when that is 0. */
+long uenc_mha_fwd_workspace_floats(int B, int H, int Lq, int S);
+int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
+                 long v_rs, const unsigned char* mask, long mask_rs, void* out, long o_bs, long o_rs, float* lse,
+                 float* workspace, int B, int H, int Lq, int S, float scale, void* stream);
+/* dq (B,Lq,*) fp32 ACCUMULATED (caller zeroes); dk, dv (B,S,*) bf16 overwritten for every key and head. */
+int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
+                 long v_rs, const unsigned char* mask, long mask_rs, const void* out, long o_bs, long o_rs,
+                 const float* lse, const void* dout, long do_bs, long do_rs, float* dq, long dq_bs, long dq_rs, void* dk,
+                 long dk_bs, long dk_rs, void* dv, long dv_bs, long dv_rs, int B, int H, int Lq, int S, float scale,
+                 void* stream);
+
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */
 int uenc_prof_collect(int kind /* 0 gemm_nt, 1 gemm_tn */, double* ms_total, double* flops_total, long* launches);

@@ -201,3 +201,33 @@ def test_mha_module(ops, Lq, S, masked):
     _check("dq", q.grad.cpu(), qc.grad, 4e-2); _check("dk", k.grad.cpu(), kc.grad, 4e-2); _check("dv", v.grad.cpu(), vc.grad, 4e-2)
     for kk, prm in m.named_parameters():
         _check(kk, prm.grad.cpu(), sd["a." + kk].grad, 4e-2)
+
+
+@pytest.mark.parametrize("B,Lq,S,masked", [(1, 149, 20000, False), (2, 200, 777, True), (1, 16, 64, True), (2, 150, 6, True)])
+def test_mha_core_split_kv_and_slices(ops, B, Lq, S, masked):
+    """Attention core alone vs fp32 math: many key splits + combine, > 160 queries (two slices), tiny / ragged S,
+    strided (packed) q / k inputs, rows whose keys are all blocked in some splits."""
+    nH, E = 8, 256
+    qk = _r(B, max(Lq, S), 2 * E, seed=1).to(torch.bfloat16)
+    q = qk[:, :Lq, :E].detach().requires_grad_()
+    k = qk[:, :S, E:].detach().requires_grad_()
+    v = _r(B, S, E, seed=2).to(torch.bfloat16).requires_grad_()
+    mask = None
+    if masked:
+        mask = (torch.rand(B, Lq, S, generator=torch.Generator().manual_seed(3)) < 0.7).cuda()
+        mask[:, :, : max(1, S // 3)] &= torch.rand(B, Lq, 1, generator=torch.Generator().manual_seed(4)).cuda() < 0.5
+        mask = mask & ~mask.all(-1, keepdim=True)
+    out = ops.attention(q, k, v, nH, mask)
+    dy = _r(B, Lq, E, seed=5).to(torch.bfloat16)
+    out.backward(dy)
+    q2, k2, v2 = (t.detach().float().requires_grad_() for t in (q, k, v))
+    qh = q2.view(B, Lq, nH, 32).transpose(1, 2) * 32 ** -0.5
+    a = qh @ k2.view(B, S, nH, 32).transpose(1, 2).transpose(-1, -2)
+    if masked:
+        a = a.masked_fill(mask[:, None], float("-inf"))
+    ref = (a.softmax(-1) @ v2.view(B, S, nH, 32).transpose(1, 2)).transpose(1, 2).reshape(B, Lq, E)
+    ref.backward(dy.float())
+    _check("out", out, ref, 1.5e-2)
+    _check("dq", q.grad, q2.grad, 3e-2)
+    _check("dk", k.grad, k2.grad, 3e-2)
+    _check("dv", v.grad, v2.grad, 3e-2)

@@ -1,24 +1,76 @@
-"""Decoder multi-head attention core (self-attention over 150 queries, masked cross-attention over
-2k-32k keys, class-transformer cross-attention over 131k keys).
+"""Decoder multi-head attention core on the HIP kernels of csrc/mha.hip.
 
-TRANSITIONAL: until `csrc/mha.hip` lands this routes through torch's ROCm SDPA on the GPU (never a
-CPU path).  DESIGN.md lists it under "not yet HIP".
+q (B, Lq, E), k / v (B, S, E) bf16 with heads interleaved in E (head_dim 32), any row / batch strides
+(slices of packed in-projection outputs are read in place); mask (B, Lq, S) bool, True = blocked, shared
+by all heads.  Forward = split-KV flash attention + combine; backward = dQ kernel + dK/dV kernel.
 """
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
+
+from .capi import check, lib, stream_ptr
+
+
+def _strided(t: torch.Tensor) -> torch.Tensor:
+    """(B, L, E) with unit inner stride and 16-byte aligned rows, copying only if necessary."""
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    if t.stride(2) != 1 or t.stride(1) % 8 or t.stride(0) % 8 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _mask_bytes(mask: Optional[torch.Tensor]):
+    if mask is None:
+        return None, 0
+    m = mask.to(torch.uint8) if mask.dtype != torch.bool else mask.view(torch.uint8)
+    S = m.shape[-1]
+    if S % 4 or not m.is_contiguous():
+        Sp = -(-S // 4) * 4
+        m = torch.nn.functional.pad(m, (0, Sp - S)).contiguous()
+    return m, m.shape[-1]
+
+
+class MHACoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, nheads, mask):
+        q, k, v = _strided(q), _strided(k), _strided(v)
+        B, Lq, E = q.shape
+        S = k.shape[1]
+        assert E == nheads * 32, "the HIP attention kernels are built for head_dim 32"
+        scale = 32 ** -0.5
+        m8, mrs = _mask_bytes(mask)
+        out = torch.empty((B, Lq, E), dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty((B, nheads, Lq), dtype=torch.float32, device=q.device)
+        nws = lib.uenc_mha_fwd_workspace_floats(B, nheads, Lq, S)
+        ws = torch.empty((nws,), dtype=torch.float32, device=q.device) if nws else None
+        check(lib.uenc_mha_fwd(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                               v.data_ptr(), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else 0, mrs,
+                               out.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr(),
+                               ws.data_ptr() if ws is not None else 0, B, nheads, Lq, S, scale, stream_ptr()), "mha_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, m8 if m8 is not None else torch.empty(0, device=q.device))
+        ctx.meta = (nheads, S, scale, mrs, m8 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, m8 = ctx.saved_tensors
+        nheads, S, scale, mrs, has_mask = ctx.meta
+        B, Lq, E = q.shape
+        dout = _strided(dout)
+        dq = torch.zeros((B, Lq, E), dtype=torch.float32, device=q.device)
+        dk = torch.empty((B, S, E), dtype=torch.bfloat16, device=q.device)
+        dv = torch.empty((B, S, E), dtype=torch.bfloat16, device=q.device)
+        check(lib.uenc_mha_bwd(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                               v.data_ptr(), v.stride(0), v.stride(1), m8.data_ptr() if has_mask else 0, mrs,
+                               out.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr(),
+                               dout.data_ptr(), dout.stride(0), dout.stride(1),
+                               dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1),
+                               dv.data_ptr(), dv.stride(0), dv.stride(1), B, nheads, Lq, S, scale, stream_ptr()), "mha_bwd")
+        return dq.to(torch.bfloat16), dk, dv, None, None
 
 
 def mha(q, k, v, nheads: int, mask: Optional[torch.Tensor] = None):
-    B, Lq, E = q.shape
-    S = k.shape[1]
-    hd = E // nheads
     if not q.is_cuda:
         raise RuntimeError("uenc attention runs on the GPU only")
-    qh = q.reshape(B, Lq, nheads, hd).transpose(1, 2)
-    kh = k.reshape(B, S, nheads, hd).transpose(1, 2)
-    vh = v.reshape(B, S, nheads, hd).transpose(1, 2)
-    am = None if mask is None else ~mask[:, None]
-    o = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=am)
-    return o.transpose(1, 2).reshape(B, Lq, E)
+    return MHACoreFn.apply(q, k, v, nheads, mask)
