@@ -76,9 +76,10 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         ref = torch.cat(pts, 1)
         return ref[:, :, None] * valid_ratios[:, None]
 
-    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, shapes_list=None):
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, shapes_list=None, ref=None):
         out = src
-        ref = self.get_reference_points(shapes_list, valid_ratios, src.device).contiguous()
+        if ref is None:
+            ref = self.get_reference_points(shapes_list, valid_ratios, src.device).contiguous()
         for layer in self.layers:
             out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
         return out
@@ -92,6 +93,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         self.encoder = MSDeformAttnTransformerEncoder(
             (d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, enc_n_points), num_encoder_layers)
         self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self._geometry = {}
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -106,10 +108,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         B = srcs_tok[0].shape[0]
         src = torch.cat(srcs_tok, 1)
         pos = torch.cat([p + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_tok)], 1)
-        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
-        valid_ratios = torch.ones((B, len(shapes_list), 2), dtype=torch.float32, device=device)   # no padding masks on this path
-        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None, shapes_list)
+        key = (tuple(shapes_list), B, str(device))
+        geo = self._geometry.get(key)
+        if geo is None:       # level geometry lives on the device; built once per shape (no per-step host-to-device copies)
+            spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            valid_ratios = torch.ones((B, len(shapes_list), 2), dtype=torch.float32, device=device)   # no padding masks here
+            ref = MSDeformAttnTransformerEncoder.get_reference_points(shapes_list, valid_ratios, device).contiguous()
+            geo = (spatial_shapes, level_start_index, valid_ratios, ref)
+            self._geometry[key] = geo
+        spatial_shapes, level_start_index, valid_ratios, ref = geo
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None, shapes_list, ref)
         return memory, spatial_shapes, level_start_index, valid_ratios
 
 

@@ -42,6 +42,7 @@ class OneFormer(nn.Module):
         self.test_topk_per_image = test_topk_per_image
         self.task_tokenizer = Tokenize(max_seq_len=task_seq_len)
         self.is_demo = is_demo
+        self._task_cache = {}
 
     @classmethod
     def from_config(cls, cfg):
@@ -65,14 +66,24 @@ class OneFormer(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    def _task_tokens(self, task: str) -> torch.Tensor:
+        """(1, 77) float token ids on the device; cached per prompt (no host-to-device copy in the steady state,
+        which also keeps the step capturable into a HIP graph)."""
+        key = (task, str(self.device))
+        t = self._task_cache.get(key)
+        if t is None:
+            t = self.task_tokenizer(task).to(self.device).unsqueeze(0).float()
+            self._task_cache[key] = t
+        return t
+
     def forward_features(self, batched_inputs: List[dict]):
         """Normalise, pad to a multiple of 32, task embedding, backbone, head.  Returns (outputs, ImageList)."""
         seg = [x for x in batched_inputs if x["type"] == "segmentation"]
         images = [x["left_image"].to(self.device) for x in seg]
         images = [(x - self.pixel_mean) / self.pixel_std for x in images]
         images = ImageList.from_tensors(images, self.size_divisibility)
-        tasks = torch.cat([self.task_tokenizer(x["task"]).to(self.device).unsqueeze(0) for x in seg], dim=0)
-        tasks = self.task_mlp(tasks.float())
+        tasks = torch.cat([self._task_tokens(x["task"]) for x in seg], dim=0)
+        tasks = self.task_mlp(tasks)
         features = self.backbone(images.tensor)
         outputs, _ = self.sem_seg_head(features, None, tasks)
         return outputs, images
