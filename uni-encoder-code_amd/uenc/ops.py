@@ -112,10 +112,20 @@ def _bias_pad(b: Optional[torch.Tensor], Np: int) -> Optional[torch.Tensor]:
     return torch.nn.functional.pad(b.detach(), (0, Np - b.numel()))
 
 
+_BIG_M = 8192      # from this many rows on, an fp32 operand is first copied to bf16: the LDS-DMA GEMM kernels read bf16 only
+
+
+def _as_bf16_operand(t2: torch.Tensor) -> torch.Tensor:
+    if t2.dtype == F32 and t2.shape[0] >= _BIG_M and t2.is_contiguous() and t2.numel() % 8 == 0:
+        return K.cast_bf16(t2)
+    return t2
+
+
 def _wgrad(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rows=None):
     """Accumulate dW (+ db) of out = x W^T + b into the parameters' .grad."""
     if not w.requires_grad and (b is None or not b.requires_grad):
         return
+    dy2, x2 = _as_bf16_operand(dy2), _as_bf16_operand(x2)
     N, Kd = dy2.shape[1], x2.shape[1]
     gw = grad_buf(w).view(w.shape[0], -1)
     if rows is not None:
@@ -146,7 +156,7 @@ def _fwd_gemm(x2, w, b, rows, **kw):
     w16 = CACHE.mat(w, rows)
     N = (rows[1] - rows[0]) if rows is not None else w.shape[0]
     bb = b.detach()[rows[0]:rows[1]] if (b is not None and rows is not None) else (b.detach() if b is not None else None)
-    xp = _pad_cols(x2)
+    xp = _as_bf16_operand(_pad_cols(x2))
     if w16.shape[0] != N:
         bb = _bias_pad(bb, w16.shape[0])
     out = K.gemm_nt(xp, w16, bias=bb, **kw)
@@ -156,7 +166,7 @@ def _fwd_gemm(x2, w, b, rows, **kw):
 def _dgrad_gemm(dy2, w, rows, **kw):
     wt = CACHE.mat_t(w, rows)                     # (Kp, Np)
     Kd = w.reshape(w.shape[0], -1).shape[1]
-    dyp = _pad_cols(dy2)
+    dyp = _as_bf16_operand(_pad_cols(dy2))
     out = K.gemm_nt(dyp if dyp.shape[1] == wt.shape[1] else torch.nn.functional.pad(dyp, (0, wt.shape[1] - dyp.shape[1])),
                     wt, **kw)
     return out if wt.shape[0] == Kd else out[:, :Kd]
