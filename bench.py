@@ -139,7 +139,7 @@ def main():
         ops.CACHE.invalidate()                 # weights change every training step: re-cast inside the step
         out, images = model.forward_features(batch)
         with torch.no_grad():                  # reference :255-263, part of the forward it times
-            F.interpolate(out["pred_masks"], size=images.tensor.shape[-2:], mode="bilinear", align_corners=False)
+            model.upsample_masks(out["pred_masks"], images.tensor.shape[-2:])
         loss = synthetic_loss(out)
         loss.backward()
         buckets.finish()

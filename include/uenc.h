@@ -44,6 +44,10 @@ const char* uenc_arch(void); /* "gfx950" */
 int uenc_cast_f32_bf16(const float* src, void* dst, long n /* multiple of 8 */, void* stream);
 int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C][R] bf16 */, int R, int C, void* stream);
 
+/* bilinear resize, align_corners = False, of NC fp32 planes (Hi, Wi) -> (Ho, Wo), Wo % 4 == 0: the final mask upsample
+ * F.interpolate(mask_pred_results, size=..., mode="bilinear") of model/oneformer_model.py:255-263 (forward only). */
+int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, void* stream);
+
 /* ---- Linear layers ---------------------------------------------------------------------------------
  * C[m][n] = epi(alpha * (sum_k A[m][k] W[n][k] + bias[n])).  A fp32|bf16 [M][K] (lda), W bf16 [N][K] (ldw),
  * C fp32|bf16 [M][N] (ldc).  K % 8 == 0, N % 4 == 0, 16-byte aligned bases.  splitk > 1 or accumulate != 0

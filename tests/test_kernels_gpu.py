@@ -289,3 +289,10 @@ def test_gemm_tn_large_tile_path(K, M, N, K_, variant, monkeypatch):
     dwi = torch.zeros(N, K_, device="cuda")
     K.gemm_tn(dyi, xi, dwi, None, splitm=1)
     _close(dwi, dyi.float().t() @ xi.float(), 0, 0)
+
+
+@pytest.mark.parametrize("shape,size", [((2, 5, 16, 24), (64, 96)), ((1, 3, 7, 9), (28, 36)), ((1, 2, 10, 6), (17, 20))])
+def test_upsample_bilinear(K, shape, size):
+    x = _r(*shape, seed=1)
+    want = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    _close(K.upsample_bilinear(x, size), want, 1e-5, 1e-5)

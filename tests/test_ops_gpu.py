@@ -231,3 +231,16 @@ def test_mha_core_split_kv_and_slices(ops, B, Lq, S, masked):
     _check("dq", q.grad, q2.grad, 3e-2)
     _check("dk", k.grad, k2.grad, 3e-2)
     _check("dv", v.grad, v2.grad, 3e-2)
+
+
+def test_conv3x3_fn(ops):
+    B, H, W, Ci, Co = 2, 20, 28, 64, 128
+    x = _r(B, H, W, Ci, seed=1).requires_grad_()
+    w = _p(Co, Ci, 3, 3, seed=2, scale=(9 * Ci) ** -0.5)
+    y = ops.conv3x3(x, w)
+    dy = _r(B, H, W, Co, seed=3)
+    y.backward(dy)
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    y2 = F.conv2d(x2.permute(0, 3, 1, 2), w2, padding=1).permute(0, 2, 3, 1)
+    y2.backward(dy)
+    _check("y", y, y2, 1e-2); _check("dx", x.grad, x2.grad, 1.5e-2); _check("dw", w.grad, w2.grad, 1.5e-2)

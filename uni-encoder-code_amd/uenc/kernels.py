@@ -195,3 +195,14 @@ def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out):
                                      attn.data_ptr(), grad_out.data_ptr(), dt(grad_out), gv.data_ptr(), gl.data_ptr(),
                                      ga.data_ptr(), B, S, M, D, L, Lq, P, stream_ptr()), "msdeform_attn_bwd")
     return gv, gl, ga
+
+
+def upsample_bilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """(N, C, Hi, Wi) fp32 -> (N, C, Ho, Wo), bilinear, align_corners=False (forward only; Wo % 4 == 0)."""
+    N, C, Hi, Wi = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    assert x.dtype == torch.float32 and x.is_cuda and Wo % 4 == 0
+    x = x.contiguous()
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.uenc_upsample_bilinear(x.data_ptr(), out.data_ptr(), N * C, Hi, Wi, Ho, Wo, stream_ptr()), "upsample_bilinear")
+    return out

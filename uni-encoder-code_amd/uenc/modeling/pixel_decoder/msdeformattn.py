@@ -204,7 +204,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
             lat, outc = self.lateral_convs[idx], self.output_convs[idx]
             cur = _conv1x1_gn(_tokens(x), lat, lat.norm, H, W).transpose(1, 2).reshape(B, -1, H, W)
             yy = cur + F.interpolate(out[-1], size=(H, W), mode="bilinear", align_corners=False)
-            out.append(outc(yy))
+            if outc.kernel_size == (3, 3) and outc.bias is None and outc.stride == (1, 1) and outc.padding == (1, 1):
+                z = ops.conv3x3(yy.permute(0, 2, 3, 1), outc.weight).permute(0, 3, 1, 2)        # im2col + MFMA GEMM
+                if outc.norm is not None:
+                    z = outc.norm(z)
+                out.append(outc.activation(z) if outc.activation is not None else z)
+            else:
+                out.append(outc(yy))
         multi_scale_features = out[:self.oneformer_num_feature_levels]
         last = out[-1]
         B, _, H, W = last.shape

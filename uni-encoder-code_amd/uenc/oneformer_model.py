@@ -88,13 +88,21 @@ class OneFormer(nn.Module):
         outputs, _ = self.sem_seg_head(features, None, tasks)
         return outputs, images
 
+    @staticmethod
+    def upsample_masks(pred_masks, size):
+        """x4 bilinear upsample of the mask logits to the padded input size (reference :255-263), HIP kernel when no
+        gradient is needed (inference / the benchmark's forward), autograd-capable ATen path otherwise."""
+        if pred_masks.requires_grad and torch.is_grad_enabled() or size[1] % 4:
+            return F.interpolate(pred_masks, size=size, mode="bilinear", align_corners=False)
+        from . import kernels as K
+        return K.upsample_bilinear(pred_masks.detach().float(), size)
+
     def forward(self, batched_inputs: List[dict]):
         if any(e["type"] == "sequence" for e in batched_inputs):
             raise NotImplementedError("the 'sequence' (depth / pose / motion) branch is out of the hot-path scope, SURVEY.md §8f")
         outputs, images = self.forward_features(batched_inputs)
         mask_cls_results = outputs["pred_logits"]
-        mask_pred_results = F.interpolate(outputs["pred_masks"], size=images.tensor.shape[-2:], mode="bilinear",
-                                          align_corners=False)
+        mask_pred_results = self.upsample_masks(outputs["pred_masks"], images.tensor.shape[-2:])
         results = []
         seg = [x for x in batched_inputs if x["type"] == "segmentation"]
         for mask_cls, mask_pred, inp, image_size in zip(mask_cls_results, mask_pred_results, seg, images.image_sizes):

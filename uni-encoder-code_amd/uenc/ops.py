@@ -452,3 +452,58 @@ def attention(q, k, v, nheads: int, mask: Optional[torch.Tensor] = None) -> torc
     """softmax(q k^T / sqrt(d) [blocked where mask]) v, heads interleaved in E.  -> (B, Lq, E) bf16."""
     from .attention import mha
     return mha(q, k, v, nheads, mask)
+
+
+# --------------------------------------------------------------------------------------------
+# 3x3 convolution (stride 1, pad 1, no bias) on channels-last maps as im2col + MFMA GEMM
+# --------------------------------------------------------------------------------------------
+class Conv3x3Fn(torch.autograd.Function):
+    """The single 3x3 conv of the FPN (reference pixel_decoder/msdeformattn.py:293-302 `layer_1`, 154 GFLOP per image
+    at 1/4 resolution).  x (B, H, W, Cin) channels-last; weight (Cout, Cin, 3, 3).  Forward: one strided gather
+    into the (B*H*W, 9*Cin) bf16 patch matrix, then the 256x256 LDS-DMA GEMM; backward: dgrad GEMM + 9 shifted
+    adds (col2im), wgrad through the token-contraction GEMM on the saved patch matrix."""
+
+    @staticmethod
+    def _wmat(weight):
+        return CACHE._get(weight, "c3", lambda: K.cast_bf16(weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()))
+
+    @staticmethod
+    def _wmat_t(weight):
+        return CACHE._get(weight, "c3t", lambda: K.cast_transpose_bf16(
+            weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()))
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        B, H, W, C = x.shape
+        xp = torch.nn.functional.pad(x.to(BF16), (0, 0, 1, 1, 1, 1))                       # (B, H+2, W+2, C)
+        sB, sH, sW, sC = xp.stride()
+        col = xp.as_strided((B, H, W, 3, 3, C), (sB, sH, sW, sH, sW, sC)).reshape(B * H * W, 9 * C)   # one gather copy
+        out = K.gemm_nt(col, Conv3x3Fn._wmat(weight), out_dtype=F32)
+        ctx.save_for_backward(col, weight)
+        ctx.shape = (B, H, W, C)
+        return out.view(B, H, W, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, weight = ctx.saved_tensors
+        B, H, W, C = ctx.shape
+        Co = weight.shape[0]
+        dy2 = K.cast_bf16(dy.reshape(B * H * W, Co).contiguous().float())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = K.gemm_nt(dy2, Conv3x3Fn._wmat_t(weight)).view(B, H, W, 3, 3, C)          # (M, 9*Cin) bf16
+            dxp = torch.zeros((B, H + 2, W + 2, C), dtype=F32, device=dy.device)
+            for ky in range(3):
+                for kx in range(3):
+                    dxp[:, ky:ky + H, kx:kx + W].add_(dcol[:, :, :, ky, kx])
+            dx = dxp[:, 1:H + 1, 1:W + 1]
+        if weight.requires_grad:
+            dw = torch.zeros((Co, 9 * C), dtype=F32, device=dy.device)
+            K.gemm_tn(dy2, col, dw, None)
+            grad_buf(weight).add_(dw.view(Co, 3, 3, C).permute(0, 3, 1, 2))
+            _notify(weight)
+        return dx, None
+
+
+def conv3x3(x_nhwc, weight):
+    return Conv3x3Fn.apply(x_nhwc, weight)
