@@ -136,7 +136,7 @@ def main():
 
     def step():
         buckets.zero_grad()
-        ops.CACHE.invalidate()                 # weights change every training step: re-cast inside the step
+        ops.CACHE.refresh()                    # weights change every training step: every bf16 operand copy is re-cast
         out, images = model.forward_features(batch)
         with torch.no_grad():                  # reference :255-263, part of the forward it times
             model.upsample_masks(out["pred_masks"], images.tensor.shape[-2:])

@@ -44,6 +44,11 @@ const char* uenc_arch(void); /* "gfx950" */
 int uenc_cast_f32_bf16(const float* src, void* dst, long n /* multiple of 8 */, void* stream);
 int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C][R] bf16 */, int R, int C, void* stream);
 
+/* batched cast: `table` = n device-resident descriptors {const float* src; bf16* dst; int rows, cols, transpose, tiles_c;
+ * long tile_begin;} (40 bytes each; tiles_c = ceil(cols / 64), tile_begin = exclusive prefix sum of 64x64 tile counts);
+ * dst is [rows][cols] or, if transpose, [cols][rows].  One launch refreshes every bf16 weight operand of a model. */
+int uenc_cast_multi(const void* table, int n, long total_tiles, void* stream);
+
 /* bilinear resize, align_corners = False, of NC fp32 planes (Hi, Wi) -> (Ho, Wo), Wo % 4 == 0: the final mask upsample
  * F.interpolate(mask_pred_results, size=..., mode="bilinear") of model/oneformer_model.py:255-263 (forward only). */
 int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, void* stream);

@@ -244,3 +244,22 @@ def test_conv3x3_fn(ops):
     y2 = F.conv2d(x2.permute(0, 3, 1, 2), w2, padding=1).permute(0, 2, 3, 1)
     y2.backward(dy)
     _check("y", y, y2, 1e-2); _check("dx", x.grad, x2.grad, 1.5e-2); _check("dw", w.grad, w2.grad, 1.5e-2)
+
+
+def test_param_cache_refresh(ops):
+    """One batched launch must leave every cached bf16 operand equal to a fresh cast of the updated master weight."""
+    ops.CACHE.invalidate()
+    w1, w2, b = _p(96, 200, seed=1), _p(768, 256, seed=2), _p(600, seed=3)
+    odd = _p(20, 77, seed=4)
+    got = [ops.CACHE.mat(w1), ops.CACHE.mat_t(w1), ops.CACHE.mat(w2, (256, 512)), ops.CACHE.mat_t(w2, (512, 768)), ops.CACHE.vec16(b),
+           ops.CACHE.mat(odd)]
+    with torch.no_grad():
+        for t in (w1, w2, b, odd):
+            t.add_(1.0)
+    ops.CACHE.refresh()
+    assert ops.CACHE.mat(w1).data_ptr() == got[0].data_ptr()           # refreshed in place, no re-allocation
+    for g, want in zip(got[:5], [w1, w1.t(), w2[256:512], w2[512:768].t(), b]):
+        assert torch.equal(g, want.detach().to(torch.bfloat16))
+    o = ops.CACHE.mat(odd)                                              # padded entries are re-made lazily
+    assert torch.equal(o[:20, :77], odd.detach().to(torch.bfloat16)) and o.shape == (24, 80)
+    ops.CACHE.invalidate()

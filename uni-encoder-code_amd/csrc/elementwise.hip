@@ -82,5 +82,51 @@ extern "C" int uenc_upsample_bilinear(const float* in, float* out, long NC, int 
     UENC_LAUNCH_RET();
 }
 
+// Batched refresh of the bf16 operand copies of many fp32 master weights in ONE launch (plain or transposed), instead
+// of ~650 tiny cast launches per training step.  `table` (device memory) holds one descriptor per tensor; a 64x64 tile
+// index is mapped to its tensor by binary search over the exclusive prefix sum of tile counts.
+struct CastDesc { const float* src; bf16* dst; int rows, cols, transpose, tiles_c; long tile_begin; };
+
+__global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restrict__ table, int n, long total_tiles) {
+    __shared__ float tile[64][65];
+    for (long tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid].tile_begin <= tix) lo = mid; else hi = mid - 1;
+        }
+        const CastDesc d = table[lo];
+        const int local = (int)(tix - d.tile_begin);
+        const int tr = local / d.tiles_c, tc = local - tr * d.tiles_c;
+        const int r0 = tr * 64, c0 = tc * 64;
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        if (!d.transpose) {
+            for (int i = ty; i < 64; i += 4) {
+                const int r = r0 + i, c = c0 + tx;
+                if (r < d.rows && c < d.cols) d.dst[(long)r * d.cols + c] = (bf16)d.src[(long)r * d.cols + c];
+            }
+        } else {
+            __syncthreads();
+            for (int i = ty; i < 64; i += 4) {
+                const int r = r0 + i, c = c0 + tx;
+                tile[i][tx] = (r < d.rows && c < d.cols) ? d.src[(long)r * d.cols + c] : 0.f;
+            }
+            __syncthreads();
+            for (int i = ty; i < 64; i += 4) {
+                const int c = c0 + i, r = r0 + tx;
+                if (c < d.cols && r < d.rows) d.dst[(long)c * d.rows + r] = (bf16)tile[tx][i];
+            }
+        }
+    }
+}
+
+// table: n descriptors of 40 bytes {src, dst, rows, cols, transpose, tiles_c, tile_begin} in device memory.
+extern "C" int uenc_cast_multi(const void* table, int n, long total_tiles, hipStream_t stream) {
+    UENC_CHECK_ARG(table && n > 0 && total_tiles > 0);
+    long blocks = total_tiles < 8192 ? total_tiles : 8192;
+    hipLaunchKernelGGL(cast_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const CastDesc*)table, n, total_tiles);
+    UENC_LAUNCH_RET();
+}
+
 extern "C" int uenc_version(void) { return 1; }
 extern "C" const char* uenc_arch(void) { return "gfx950"; }

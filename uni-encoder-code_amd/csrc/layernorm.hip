@@ -201,7 +201,7 @@ extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, i
     p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32);
     p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C;
     long blocks = (M + 3) / 4;
-    if (blocks > 2048) blocks = 2048;     // 8 blocks per CU: enough rows in flight to cover HBM latency
+    if (blocks > 1024) blocks = 1024;
     const int nv = (C + 255) / 256;
     const size_t shm = (size_t)2 * C * sizeof(float);
     dim3 grid((unsigned)blocks), block(256);

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "uenc_prof_collect": [c_i, c_p, c_p, c_p],
     "uenc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
     "uenc_cast_transpose_f32_bf16": [c_p, c_p, c_i, c_i, c_p],
+    "uenc_cast_multi": [c_p, c_i, c_l, c_p],
     "uenc_upsample_bilinear": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_nt": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_i, c_p],
     "uenc_gemm_tn": [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],

@@ -23,16 +23,22 @@ BF16, F32 = torch.bfloat16, torch.float32
 # parameter operand cache and gradient buffers
 # --------------------------------------------------------------------------------------------
 class ParamCache:
-    """bf16 (optionally transposed / zero-padded) copies of fp32 parameters, keyed by version."""
+    """bf16 (optionally transposed / zero-padded) copies of fp32 parameters, keyed by version.
+
+    `refresh()` re-casts every cached copy in place with ONE batched kernel launch (instead of one tiny launch per
+    tensor): call it after each optimizer step; entries are otherwise re-made lazily when a parameter's version or
+    storage changed."""
 
     def __init__(self):
         self._store = {}
         self.casts = 0
+        self._table = None          # (device descriptor tensor, n, total_tiles, keys)
 
     def invalidate(self):
         self._store.clear()
+        self._table = None
 
-    def _get(self, p: torch.Tensor, kind, make):
+    def _get(self, p: torch.Tensor, kind, make, plan=None):
         key = (id(p), kind)
         ent = self._store.get(key)
         # id() of a dead tensor can be reused by a new one (with the same storage address and version 0):
@@ -41,37 +47,71 @@ class ParamCache:
             return ent[2]
         t = make()
         self.casts += 1
-        self._store[key] = (p._version, p.data_ptr(), t, weakref.ref(p))
+        self._store[key] = (p._version, p.data_ptr(), t, weakref.ref(p), plan)
+        self._table = None
         return t
+
+    @staticmethod
+    def _mat_view(p, rows):
+        w = p.detach().reshape(p.shape[0], -1)
+        return w if rows is None else w[rows[0]:rows[1]]
 
     def mat(self, p: torch.Tensor, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
         """(N, K) bf16 view of a Linear / 1x1-conv weight, rows [a, b) if given; K, N padded to 8."""
+        w = self._mat_view(p, rows)
+        N, Kd = w.shape
+        aligned = N % 8 == 0 and Kd % 8 == 0
+
         def make():
-            w = p.detach().reshape(p.shape[0], -1)
-            if rows is not None:
-                w = w[rows[0]:rows[1]]
-            N, Kd = w.shape
-            Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
-            if (Np, Kp) != (N, Kd):
-                w = torch.nn.functional.pad(w, (0, Kp - Kd, 0, Np - N))
-            return K.cast_bf16(w.contiguous())
-        return self._get(p, ("m", rows), make)
+            ww = w if aligned else torch.nn.functional.pad(w, (0, -Kd % 8, 0, -N % 8))
+            return K.cast_bf16(ww.contiguous())
+        plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 0) if aligned else None
+        return self._get(p, ("m", rows), make, plan)
 
     def mat_t(self, p: torch.Tensor, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
         """(K, N) bf16: the transposed operand the dgrad GEMM reads."""
+        w = self._mat_view(p, rows)
+        N, Kd = w.shape
+        aligned = N % 8 == 0 and Kd % 8 == 0
+
         def make():
-            w = p.detach().reshape(p.shape[0], -1)
-            if rows is not None:
-                w = w[rows[0]:rows[1]]
-            N, Kd = w.shape
-            Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
-            if (Np, Kp) != (N, Kd):
-                w = torch.nn.functional.pad(w, (0, Kp - Kd, 0, Np - N))
-            return K.cast_transpose_bf16(w.contiguous())
-        return self._get(p, ("t", rows), make)
+            ww = w if aligned else torch.nn.functional.pad(w, (0, -Kd % 8, 0, -N % 8))
+            return K.cast_transpose_bf16(ww.contiguous())
+        plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 1) if aligned else None
+        return self._get(p, ("t", rows), make, plan)
 
     def vec16(self, p: torch.Tensor) -> torch.Tensor:
-        return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()))
+        return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()), (0, 1, p.numel(), 0))
+
+    def refresh(self):
+        """Re-cast every cached operand copy from its (updated) fp32 master, in one launch."""
+        import numpy as np
+        from .capi import check, lib, stream_ptr
+        if not self._store:
+            return
+        dead = [k for k, e in self._store.items() if e[3]() is None or e[4] is None or e[3]().data_ptr() != e[1]]
+        for k in dead:                              # padded / special entries and moved storages are re-made lazily
+            del self._store[k]
+            self._table = None
+        if not self._store:
+            return
+        if self._table is None:
+            desc = np.zeros(len(self._store), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                                     ("tr", "<i4"), ("tc", "<i4"), ("tb", "<i8")])
+            tb, keys, dev = 0, [], None
+            for i, (k, e) in enumerate(self._store.items()):
+                off, rows, cols, tr = e[4]
+                desc[i] = (e[1] + off, e[2].data_ptr(), rows, cols, tr, -(-cols // 64), tb)
+                tb += -(-rows // 64) * -(-cols // 64)
+                keys.append(k)
+                dev = e[2].device
+            tab = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+            self._table = (tab, len(keys), tb, keys)
+        tab, n, total, keys = self._table
+        check(lib.uenc_cast_multi(tab.data_ptr(), n, total, stream_ptr()), "cast_multi")
+        for k in keys:
+            e = self._store[k]
+            self._store[k] = (e[3]()._version, e[1], e[2], e[3], e[4])
 
 
 CACHE = ParamCache()
