@@ -53,6 +53,11 @@ int uenc_cast_multi(const void* table, int n, long total_tiles, void* stream);
  * F.interpolate(mask_pred_results, size=..., mode="bilinear") of model/oneformer_model.py:255-263 (forward only). */
 int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, void* stream);
 
+/* attention mask of the masked-attention decoder: mask[r][oy][ox] = bilinear(logits[r], (Ho, Wo))[oy][ox] < 0 (1 = blocked),
+ * rows that would be fully blocked are cleared (reference oneformer_transformer_decoder.py:497-505 and :454).
+ * logits fp32 [rows][Hi][Wi]; mask u8 [rows][Ho][Wo]; Wo % 4 == 0. */
+int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, void* stream);
+
 /* ---- Linear layers ---------------------------------------------------------------------------------
  * C[m][n] = epi(alpha * (sum_k A[m][k] W[n][k] + bias[n])).  A fp32|bf16 [M][K] (lda), W bf16 [N][K] (ldw),
  * C fp32|bf16 [M][N] (ldc).  K % 8 == 0, N % 4 == 0, 16-byte aligned bases.  splitk > 1 or accumulate != 0

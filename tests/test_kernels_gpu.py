@@ -296,3 +296,21 @@ def test_upsample_bilinear(K, shape, size):
     x = _r(*shape, seed=1)
     want = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
     _close(K.upsample_bilinear(x, size), want, 1e-5, 1e-5)
+
+
+def test_attn_mask_matches_torch(K):
+    """resize + threshold + all-blocked-row fix == the torch expression of the reference (:497-505, :454)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 7, 64, 96, generator=g).cuda()
+    x[0, 2] = -x[0, 2].abs() - 0.1                      # a row that is blocked everywhere
+    x[1, 0, :, :48] = x[1, 0, :, :48].abs() + 0.1
+    for size in ((32, 48), (16, 24), (8, 12), (64, 96)):
+        am = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        ref = am.sigmoid().flatten(2) < 0.5
+        ref = ref & ~ref.all(-1, keepdim=True)
+        got = K.attn_mask(x, size)
+        assert got.dtype == torch.bool and got.shape == ref.shape
+        diff = got != ref
+        # a different rounding of the 4-tap sum may flip the sign only where the resized logit is ~0
+        assert (am.flatten(2)[diff].abs() < 1e-6).all() and diff.float().mean() < 1e-4
+        assert not got[0, 2].any()

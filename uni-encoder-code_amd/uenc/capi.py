@@ -26,6 +26,7 @@ _SIGNATURES = {
     "uenc_cast_transpose_f32_bf16": [c_p, c_p, c_i, c_i, c_p],
     "uenc_cast_multi": [c_p, c_i, c_l, c_p],
     "uenc_upsample_bilinear": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
+    "uenc_attn_mask": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_nt": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_i, c_p],
     "uenc_gemm_tn": [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p],

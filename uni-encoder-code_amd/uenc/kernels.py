@@ -197,6 +197,16 @@ def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out):
     return gv, gl, ga
 
 
+def attn_mask(logits: torch.Tensor, size) -> torch.Tensor:
+    """(B, Q, Hi, Wi) fp32 mask logits -> (B, Q, Ho*Wo) bool, True = blocked; fully blocked rows are cleared."""
+    B, Q, Hi, Wi = logits.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    assert logits.dtype == torch.float32 and logits.is_cuda and logits.is_contiguous() and Wo % 4 == 0
+    out = torch.empty((B, Q, Ho * Wo), dtype=torch.bool, device=logits.device)
+    check(lib.uenc_attn_mask(logits.data_ptr(), out.data_ptr(), B * Q, Hi, Wi, Ho, Wo, stream_ptr()), "attn_mask")
+    return out
+
+
 def upsample_bilinear(x: torch.Tensor, size) -> torch.Tensor:
     """(N, C, Hi, Wi) fp32 -> (N, C, Ho, Wo), bilinear, align_corners=False (forward only; Wo % 4 == 0)."""
     N, C, Hi, Wi = x.shape

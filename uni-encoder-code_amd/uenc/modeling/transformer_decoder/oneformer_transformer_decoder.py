@@ -21,6 +21,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ... import kernels as K
 from ... import ops
 from ...d2 import Conv2d, Registry, configurable
 from .position_encoding import PositionEmbeddingSine
@@ -291,7 +292,7 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
             lvl = i % self.num_feature_levels
             if self.forced_attn_masks is not None:
                 attn_mask = self.forced_attn_masks[i]
-            attn_mask = attn_mask & ~attn_mask.all(-1, keepdim=True)     # un-block fully blocked rows (:454)
+                attn_mask = attn_mask & ~attn_mask.all(-1, keepdim=True)     # un-block fully blocked rows (:454)
             output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_mask=attn_mask, query_pos=qe,
                                                                 key_in=kin[lvl])
             output = self.transformer_self_attention_layers[i](output, query_pos=qe)
@@ -311,7 +312,6 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         me = self.mask_embed(d, out_dtype=torch.bfloat16)
         B, Q, _ = me.shape
         outputs_mask = ops.mask_einsum(me.contiguous(), mf32, mf16, mf16_chw).view(B, Q, H4, W4)
-        with torch.no_grad():
-            am = F.interpolate(outputs_mask, size=attn_mask_target_size, mode="bilinear", align_corners=False)
-            am = am.sigmoid().flatten(2) < 0.5          # (B, Q, S) True = blocked; shared by all heads
+        # (B, Q, S) True = blocked, shared by all heads: resize + sigmoid < 0.5 + the all-blocked-row fix of :454 in one kernel
+        am = K.attn_mask(outputs_mask.detach(), attn_mask_target_size)
         return outputs_class, outputs_mask, am
