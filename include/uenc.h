@@ -55,7 +55,7 @@ int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi,
 
 /* attention mask of the masked-attention decoder: mask[r][oy][ox] = bilinear(logits[r], (Ho, Wo))[oy][ox] < 0 (1 = blocked),
  * rows that would be fully blocked are cleared (reference oneformer_transformer_decoder.py:497-505 and :454).
- * logits fp32 [rows][Hi][Wi]; mask u8 [rows][Ho][Wo]; Wo % 4 == 0. */
+ * logits fp32 [rows][Hi][Wi]; mask u8 [rows][Ho][Wo]. */
 int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, void* stream);
 
 /* ---- Linear layers ---------------------------------------------------------------------------------
@@ -116,11 +116,15 @@ int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int64_t* shapes
                            const float* loc, const float* attn, void* out, int out_dtype, int B, int S, int M, int D,
                            int L, int Lq, int P, void* stream);
 /* ms_deform_attn_backward (ms_deform_attn.h:47-66, cuh:306-408): grad_value fp32 accumulated (caller zeroes,
- * as the reference's at::zeros_like), grad_loc / grad_attn overwritten. */
+ * as the reference's at::zeros_like), grad_loc / grad_attn overwritten.  shapes_host: optional HOST copy of `shapes`,
+ * workspace: optional device scratch of uenc_msdeform_attn_bwd_workspace_bytes() bytes (both may be NULL).  With them
+ * (D == 32, L <= 4, L*P <= 16) the grad_value contributions are binned per block of value pixels and summed on chip
+ * instead of being sent to memory one float atomic per tap and channel.  Same result either way. */
 int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
                            const float* loc, const float* attn, const void* grad_out, int go_dtype, float* grad_value,
                            float* grad_loc, float* grad_attn, int B, int S, int M, int D, int L, int Lq, int P,
-                           void* stream);
+                           const int64_t* shapes_host, void* workspace, long workspace_bytes, void* stream);
+long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, int M, int D, int L, int Lq, int P);
 
 /* ---- decoder multi-head attention core (head_dim 32) --------------------------------------------------------
  * softmax(scale * q k^T [blocked where mask != 0]) v for every nn.MultiheadAttention of the transformer decoder

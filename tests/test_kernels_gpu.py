@@ -235,6 +235,50 @@ def test_msdeform_vs_oracle_random(K):
     _close(gl, l32.grad, 5e-4, 1e-4)
 
 
+@pytest.mark.parametrize("shapes_l,spread", [([(5, 9), (10, 18), (20, 36)], 3.0), ([(8, 16), (16, 32), (32, 64)], 4.0),
+                                             ([(7, 11), (13, 22), (27, 43)], 40.0), ([(24, 40)], 2.0)])
+def test_msdeform_bwd_tiled_vs_oracle(K, shapes_l, spread):
+    """Encoder case (queries = pixels of the pyramid, samples a few pixels around the query): the LDS-tiled backward,
+    with in-window and out-of-window samples, against the oracle's autograd and against the direct-atomics kernel."""
+    from oracle import torch_ref as T
+    L = len(shapes_l)
+    S = sum(h * w for h, w in shapes_l)
+    B, M, D, P = 2, 8, 32, 4
+    gen = torch.Generator().manual_seed(1)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1)
+                     .reshape(-1, 2).flip(-1) for h, w in shapes_l])                          # (S, 2) as (x, y)
+    norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32)                     # (L, 2)
+    off = (torch.rand(B, S, M, L, P, 2, generator=gen) * 2 - 1) * spread
+    off[:, :, :, :, 0] = off[:, :, :, :, 0].round()                                            # integer offsets: lh = lw = 0 taps
+    loc = (ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+    value = torch.randn(B, S, M, D, generator=gen)
+    w = torch.rand(B, S, M, L * P, generator=gen).softmax(-1).view(B, S, M, L, P)
+    v32, l32, w32 = value.clone().requires_grad_(), loc.clone().requires_grad_(), w.clone().requires_grad_()
+    want = T.ms_deform_attn_core(v32, shapes_l, l32, w32)
+    go = torch.randn(want.shape, generator=gen)
+    want.backward(go)
+    shapes = torch.tensor(shapes_l, dtype=torch.int64).cuda()
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    args = (value.cuda(), shapes, start, loc.cuda(), w.cuda(), go.cuda())
+    gv, gl, ga = K.msdeform_attn_bwd(*args, shapes_host=shapes_l)
+    scale = float(v32.grad.abs().max())
+    _close(gv, v32.grad, 2e-5 * scale + 1e-5, 1e-4)
+    _close(ga, w32.grad, 1e-4, 1e-4)
+    # (point 0 sits exactly on pixel centres, where d/dloc of the bilinear kernel is one-sided: compared below instead)
+    _close(gl[:, :, :, :, 1:], l32.grad[:, :, :, :, 1:], 5e-4 * float(l32.grad.abs().max()), 1e-4)
+    gv0, gl0, ga0 = K.msdeform_attn_bwd(*args)
+    _close(gv, gv0, 2e-5 * scale + 1e-5, 1e-4)
+    _close(gl, gl0, 1e-4 * float(gl0.abs().max()), 1e-4)
+    _close(ga, ga0, 1e-4, 1e-4)
+    # bf16 value / bf16 grad_out operands (what the pixel decoder passes)
+    a16 = (args[0].to(torch.bfloat16), shapes, start, args[3], args[4], args[5].to(torch.bfloat16))
+    gv1, gl1, ga1 = K.msdeform_attn_bwd(*a16, shapes_host=shapes_l)
+    gv2, gl2, ga2 = K.msdeform_attn_bwd(*a16)
+    _close(gv1, gv2, 2e-5 * scale + 1e-5, 1e-4)
+    _close(gl1, gl2, 1e-4 * float(gl2.abs().max()), 1e-4)
+    _close(ga1, ga2, 1e-4, 1e-4)
+
+
 def test_gemm_tn_f32_dy(K):
     dy = _r(300, 64, seed=1)
     x = _r(300, 40, seed=2)
@@ -304,7 +348,7 @@ def test_attn_mask_matches_torch(K):
     x = torch.randn(2, 7, 64, 96, generator=g).cuda()
     x[0, 2] = -x[0, 2].abs() - 0.1                      # a row that is blocked everywhere
     x[1, 0, :, :48] = x[1, 0, :, :48].abs() + 0.1
-    for size in ((32, 48), (16, 24), (8, 12), (64, 96)):
+    for size in ((32, 48), (16, 24), (8, 12), (64, 96), (2, 3), (9, 13)):
         am = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
         ref = am.sigmoid().flatten(2) < 0.5
         ref = ref & ~ref.all(-1, keepdim=True)

@@ -86,11 +86,12 @@ extern "C" int uenc_upsample_bilinear(const float* in, float* out, long NC, int 
 // resize (align_corners = False) of the (Hi, Wi) mask logits of one (image, query) row to the (Ho, Wo) key map,
 // blocked = sigmoid(v) < 0.5 <=> v < 0, and the "a fully blocked row attends everywhere" fix of :454 -- one
 // workgroup per row, so the row-wide test is a block reduction instead of a second pass over HBM.
+template <int VEC>   // VEC output pixels of a row per thread (4 when Wo % 4 == 0: one 32-bit store, else 1)
 __global__ __launch_bounds__(1024) void attn_mask_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, int Hi, int Wi,
                                                          int Ho, int Wo, float sy, float sx) {
     const float* src = in + (long)blockIdx.x * Hi * Wi;
     uint8_t* dst = out + (long)blockIdx.x * Ho * Wo;
-    const int wq = Wo >> 2, total = Ho * wq;
+    const int wq = Wo / VEC, total = Ho * wq;
     int open_any = 0;
     for (int idx = threadIdx.x; idx < total; idx += 1024) {
         const int oy = idx / wq, xq = idx - oy * wq;
@@ -102,25 +103,33 @@ __global__ __launch_bounds__(1024) void attn_mask_kernel(const float* __restrict
         const float* r1 = src + (long)y1 * Wi;
         uint32_t packed = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float fx = ((float)(xq * 4 + j) + 0.5f) * sx - 0.5f;
+        for (int j = 0; j < VEC; ++j) {
+            float fx = ((float)(xq * VEC + j) + 0.5f) * sx - 0.5f;
             fx = fx < 0.f ? 0.f : fx;
             const int x0 = min((int)fx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
             const float lx = fx - (float)x0, hx = 1.f - lx;
             const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
             packed |= (v < 0.f ? 1u : 0u) << (8 * j);
         }
-        open_any |= packed != 0x01010101u;
-        *(uint32_t*)(dst + (long)oy * Wo + xq * 4) = packed;
+        if (VEC == 4) {
+            open_any |= packed != 0x01010101u;
+            *(uint32_t*)(dst + (long)oy * Wo + xq * 4) = packed;
+        } else {
+            open_any |= packed == 0u;
+            dst[(long)oy * Wo + xq] = (uint8_t)packed;
+        }
     }
     if (!__syncthreads_or(open_any))
-        for (int idx = threadIdx.x; idx < total; idx += 1024) *(uint32_t*)(dst + (long)idx * 4) = 0u;
+        for (int idx = threadIdx.x; idx < Ho * Wo; idx += 1024) dst[idx] = 0;
 }
 
 extern "C" int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, hipStream_t stream) {
-    UENC_CHECK_ARG(logits && mask && rows > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Wo % 4 == 0 && ((uintptr_t)mask & 3) == 0);
-    hipLaunchKernelGGL(attn_mask_kernel, dim3((unsigned)rows), dim3(1024), 0, stream, logits, mask, Hi, Wi, Ho, Wo,
-                       (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    UENC_CHECK_ARG(logits && mask && rows > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    if (Wo % 4 == 0 && ((uintptr_t)mask & 3) == 0)
+        hipLaunchKernelGGL(attn_mask_kernel<4>, dim3((unsigned)rows), dim3(1024), 0, stream, logits, mask, Hi, Wi, Ho, Wo, sy, sx);
+    else
+        hipLaunchKernelGGL(attn_mask_kernel<1>, dim3((unsigned)rows), dim3(1024), 0, stream, logits, mask, Hi, Wi, Ho, Wo, sy, sx);
     UENC_LAUNCH_RET();
 }
 

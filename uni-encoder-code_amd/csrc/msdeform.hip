@@ -8,9 +8,9 @@
 //
 // HBM / gather bound: per (b,q,m) 4 taps x L*P samples x D channels.  Forward: LPG = D/4 lanes per
 // (b,q,m), 16-byte tap loads (a tap's D channels are contiguous: 128 B for D=32 fp32, one line).
-// Backward: one lane per channel so each grad_value atomic wave-instruction covers two 128-byte
-// row segments (the full-rate atomic shape, MI355X_MICROARCH.md "Global float atomics");
-// grad_loc / grad_attn are reduced over channels with wave shuffles (no LDS, no atomics).
+// Backward: one lane per channel; grad_loc / grad_attn are reduced over channels with wave shuffles (no LDS, no
+// atomics).  grad_value: direct form = one atomic wave-instruction per tap covering two 128-byte row segments (the
+// full-rate atomic shape); binned form (below) = records replayed per block of value pixels, see "backward, binned".
 // `value` may be fp32 (the reference's contract) or bf16 (half the gather bytes).
 #include "common.h"
 
@@ -83,7 +83,68 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaP p) {
     }
 }
 
-// backward: D lanes per (b,q,m) (D = 32 or 64), lane = channel
+// ---- backward, direct: D lanes per (b,q,m) (D = 16, 32 or 64), lane = channel, every tap one float atomic -------------
+struct MsdaTap {       // geometry of one sample on its level
+    int h0, w0;
+    float lh, lw, hh, hw;
+    bool y0ok, y1ok, x0ok, x1ok;
+};
+__device__ __forceinline__ bool msda_tap(float x, float y, int Hl, int Wl, MsdaTap& t) {
+    const float him = y * Hl - 0.5f, wim = x * Wl - 0.5f;
+    if (!(him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl)) return false;
+    t.h0 = (int)floorf(him); t.w0 = (int)floorf(wim);
+    t.lh = him - t.h0; t.lw = wim - t.w0; t.hh = 1.f - t.lh; t.hw = 1.f - t.lw;
+    t.y0ok = t.h0 >= 0; t.y1ok = t.h0 + 1 <= Hl - 1; t.x0ok = t.w0 >= 0; t.x1ok = t.w0 + 1 <= Wl - 1;
+    return true;
+}
+
+// The per-sample body shared by both forms: gathers the 4 taps, adds the taps selected by `direct` (bit dy*2+dx) to
+// grad_value, and returns this lane's (channel's) share of d/dx, d/dy, d/dweight.
+template <int D>
+__device__ __forceinline__ void msda_sample_bwd(const MsdaP& p, const MsdaTap& t, int Hl, int Wl, long lbase, long vstride, float top,
+                                                float w, unsigned direct, float& g_w, float& g_h, float& g_a) {
+    const float tg = top * w;
+    const long r0 = lbase + ((long)t.h0 * Wl + t.w0) * vstride;
+    const long r1 = r0 + (long)Wl * vstride;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    if (p.v_f32) {
+        const float* vp = (const float*)p.value;
+        if (t.y0ok && t.x0ok) v1 = vp[r0];
+        if (t.y0ok && t.x1ok) v2 = vp[r0 + vstride];
+        if (t.y1ok && t.x0ok) v3 = vp[r1];
+        if (t.y1ok && t.x1ok) v4 = vp[r1 + vstride];
+    } else {
+        const bf16* vp = (const bf16*)p.value;
+        if (t.y0ok && t.x0ok) v1 = (float)vp[r0];
+        if (t.y0ok && t.x1ok) v2 = (float)vp[r0 + vstride];
+        if (t.y1ok && t.x0ok) v3 = (float)vp[r1];
+        if (t.y1ok && t.x1ok) v4 = (float)vp[r1 + vstride];
+    }
+    if (direct) {
+        if ((direct & 1u) && t.y0ok && t.x0ok) atomicAdd(p.grad_value + r0, t.hh * t.hw * tg);
+        if ((direct & 2u) && t.y0ok && t.x1ok) atomicAdd(p.grad_value + r0 + vstride, t.hh * t.lw * tg);
+        if ((direct & 4u) && t.y1ok && t.x0ok) atomicAdd(p.grad_value + r1, t.lh * t.hw * tg);
+        if ((direct & 8u) && t.y1ok && t.x1ok) atomicAdd(p.grad_value + r1 + vstride, t.lh * t.lw * tg);
+    }
+    g_a = top * (t.hh * t.hw * v1 + t.hh * t.lw * v2 + t.lh * t.hw * v3 + t.lh * t.lw * v4);
+    g_w = (float)Wl * tg * (-t.hh * v1 + t.hh * v2 - t.lh * v3 + t.lh * v4);
+    g_h = (float)Hl * tg * (-t.hw * v1 - t.lw * v2 + t.hw * v3 + t.lw * v4);
+}
+
+template <int D>
+__device__ __forceinline__ void msda_store_sample_grads(const MsdaP& p, long slot, int c, float g_w, float g_h, float g_a) {
+#pragma unroll
+    for (int o = D / 2; o > 0; o >>= 1) {
+        g_w += __shfl_xor(g_w, o);
+        g_h += __shfl_xor(g_h, o);
+        g_a += __shfl_xor(g_a, o);
+    }
+    if (c == 0) {
+        *(float2*)(p.grad_loc + slot * 2) = make_float2(g_w, g_h);
+        p.grad_attn[slot] = g_a;
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaP p) {
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -92,58 +153,342 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaP p) {
     const long ngrp = (long)p.B * p.Lq * p.M;
     if (grp >= ngrp) return;       // D divides 64: whole groups leave together
     const int m = (int)(grp % p.M);
-    const long bq = grp / p.M;
-    const int b = (int)(bq / p.Lq);
+    const int b = (int)(grp / p.M / p.Lq);
     const int LP = p.L * p.P;
     const float* loc = p.loc + grp * LP * 2;
     const float* aw = p.attn + grp * LP;
     const long vstride = (long)p.M * D;
     const long vbase = (long)b * p.S * vstride + (long)m * D + c;
     const float top = p.go_f32 ? ((const float*)p.grad_out)[grp * D + c] : (float)((const bf16*)p.grad_out)[grp * D + c];
-    auto ldv = [&](long idx) -> float {
-        return p.v_f32 ? ((const float*)p.value)[idx] : (float)((const bf16*)p.value)[idx];
-    };
     for (int l = 0; l < p.L; ++l) {
         const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
         const long lbase = vbase + p.level_start[l] * vstride;
         for (int k = 0; k < p.P; ++k) {
-            const float x = loc[(l * p.P + k) * 2], y = loc[(l * p.P + k) * 2 + 1];
-            const float w = aw[l * p.P + k];
-            const float him = y * Hl - 0.5f, wim = x * Wl - 0.5f;
+            const int s = l * p.P + k;
             float g_w = 0.f, g_h = 0.f, g_a = 0.f;
-            if (him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl) {
-                const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
-                const float lh = him - h0, lw = wim - w0, hh = 1.f - lh, hw = 1.f - lw;
-                const float tg = top * w;
-                const long r0 = lbase + ((long)h0 * Wl + w0) * vstride;
-                float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-                if (h0 >= 0 && w0 >= 0) { v1 = ldv(r0); atomicAdd(p.grad_value + r0, hh * hw * tg); }
-                if (h0 >= 0 && w0 + 1 <= Wl - 1) { v2 = ldv(r0 + vstride); atomicAdd(p.grad_value + r0 + vstride, hh * lw * tg); }
-                if (h0 + 1 <= Hl - 1 && w0 >= 0) {
-                    v3 = ldv(r0 + (long)Wl * vstride);
-                    atomicAdd(p.grad_value + r0 + (long)Wl * vstride, lh * hw * tg);
+            MsdaTap t;
+            if (msda_tap(loc[s * 2], loc[s * 2 + 1], Hl, Wl, t)) msda_sample_bwd<D>(p, t, Hl, Wl, lbase, vstride, top, aw[s], 0xfu, g_w, g_h, g_a);
+            msda_store_sample_grads<D>(p, grp * LP + s, c, g_w, g_h, g_a);
+        }
+    }
+}
+
+// ---- backward, binned ------------------------------------------------------------------------------------------------
+// Every float atomic is a 64-byte transaction at the memory side, ~1.3 TB/s chip-wide whatever the launch shape
+// (MI355X_MICROARCH.md "Global float atomics"): the direct kernel sends 4 taps x L*P samples x D channels x 4 B per
+// (query, head) there -- 4.2 GB per encoder layer at 1024 x 2048, ~3 ms -- and LDS float atomics (ds_add_f32) measured
+// slower still (~3 cycles per lane).  The binned form sums on chip without float atomics.  Every level is cut into
+// 4 x 4 blocks of value pixels, one bin of records per (image, head, block):
+//   pass A (msda_bwd_bin_kernel): the gather half of the backward (grad_loc, grad_attn), 8 lanes x 4 channels per
+//     (query, head); instead of adding its 4 taps to grad_value, a sample appends ONE 24-byte record {query, tap pixels,
+//     4 tap weights} to the bin of each block its taps touch (1 - 4).  A workgroup = 32 consecutive queries of one head:
+//     its appends are first counted per bin in an LDS hash table, so a bin's counter sees one returning atomic per
+//     workgroup, not per record (integer atomics are memory-side transactions too: per-record counters cost as much as
+//     the float atomics saved);
+//   pass B (msda_bin_reduce_kernel): one wave per (bin, slice of its records) sums the records as a 16-pixel x 32-channel
+//     MFMA product (see there), then adds the block to grad_value once.  Dense (coarse) levels get several slices per bin
+//     so every wave sums a few hundred records.
+// A sample that finds its bin full adds its taps directly, as the direct kernel does, so the result does not depend on
+// how the samples are distributed -- only the speed does.
+#define MSDA_TL 4
+#define MSDA_BS 4               // block edge (pixels)
+#define MSDA_CNT_STRIDE 32      // ints between bin counters: one 128-byte line each (counters sharing a line serialise)
+#define MSDA_HASH 256
+struct MsdaRec { int q; unsigned pos; float w[4]; };      // pos: (row + 1) | (column + 1) << 8 of tap (0,0) relative to the block (-1 .. 3);
+                                                          // w[dy*2+dx] = bilinear weight x attention weight of the tap, 0 outside the level
+struct MsdaBins {
+    int nbx[MSDA_TL], boff[MSDA_TL], cap[MSDA_TL];       // blocks per row; first bin of the level; records per bin of the level
+    int nsplit[MSDA_TL], woff[MSDA_TL];                  // pass-B slices per bin; first work item of the level
+    long roff[MSDA_TL];                                  // first record slot of the level within a (image, head)
+    long rtot;                                           // record slots per (image, head)
+    int nblk, nwork;                                     // bins / pass-B work items per (image, head)
+    int* count;                                          // [B * M * nblk] x MSDA_CNT_STRIDE ints (zeroed by the launcher)
+    MsdaRec* recs;                                       // [B * M][rtot]
+};
+
+__device__ __forceinline__ void atomic_add4(float* g, const float4& v) {
+    atomicAdd(g, v.x); atomicAdd(g + 1, v.y); atomicAdd(g + 2, v.z); atomicAdd(g + 3, v.w);
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+__global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn) {
+    constexpr int D = 32;
+    __shared__ int h_key[MSDA_HASH], h_cnt[MSDA_HASH], h_base[MSDA_HASH];
+    const int tid = threadIdx.x, j8 = tid & 7, c4 = j8 * 4;
+    const int nchunk = (p.Lq + 31) / 32;
+    const int chunk = blockIdx.x % nchunk, bm = blockIdx.x / nchunk;
+    const int m = bm % p.M, b = bm / p.M;
+    const int q = chunk * 32 + (tid >> 3);
+    const bool live = q < p.Lq;
+    const long grp = ((long)b * p.Lq + (live ? q : 0)) * p.M + m;
+    const int LP = p.L * p.P;
+    const float* loc = p.loc + grp * LP * 2;
+    const float* aw = p.attn + grp * LP;
+    h_key[tid] = -1; h_cnt[tid] = 0;
+    __syncthreads();
+
+    // ---- append phase: lane j8 of a group handles samples j8 and j8 + 8, each with up to 4 record-owning taps ----
+    // code: 0 = no record; bit 31 set: bit 30 = slot taken straight from the global counter (hash table full) in bits 0-29,
+    // else hash slot << 16 | position within this workgroup's share of the bin
+    unsigned code[2][4];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int s = j8 + round * 8;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) code[round][tp] = 0u;
+        if (live && s < LP) {
+            const int l = s / p.P;
+            const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
+            MsdaTap t;
+            if (msda_tap(loc[s * 2], loc[s * 2 + 1], Hl, Wl, t)) {
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    const int dy = tp >> 1, dx = tp & 1;
+                    const int cy = t.h0 + dy, cx = t.w0 + dx;
+                    // a tap owns the record of its block unless an in-range tap of the same block precedes it
+                    const bool dup_y = dy == 1 && t.y0ok && ((t.h0 + 1) / MSDA_BS) == (t.h0 / MSDA_BS);
+                    const bool dup_x = dx == 1 && t.x0ok && ((t.w0 + 1) / MSDA_BS) == (t.w0 / MSDA_BS);
+                    if (cy >= 0 && cy < Hl && cx >= 0 && cx < Wl && !dup_y && !dup_x) {
+                        const int bin = bm * bn.nblk + bn.boff[l] + (cy / MSDA_BS) * bn.nbx[l] + cx / MSDA_BS;
+                        int h = (int)(((unsigned)bin * 2654435761u) >> 24);
+                        unsigned cd = 0u;
+                        for (int probe = 0; probe < MSDA_HASH; ++probe) {
+                            const int prev = atomicCAS(&h_key[h], -1, bin);
+                            if (prev == -1 || prev == bin) { cd = 0x80000000u | ((unsigned)h << 16) | (unsigned)atomicAdd(&h_cnt[h], 1); break; }
+                            h = (h + 1) & (MSDA_HASH - 1);
+                        }
+                        if (cd == 0u) cd = 0xc0000000u | ((unsigned)atomicAdd(bn.count + (long)bin * MSDA_CNT_STRIDE, 1) & 0x3fffffffu);
+                        code[round][tp] = cd;
+                    }
                 }
-                if (h0 + 1 <= Hl - 1 && w0 + 1 <= Wl - 1) {
-                    v4 = ldv(r0 + (long)Wl * vstride + vstride);
-                    atomicAdd(p.grad_value + r0 + (long)Wl * vstride + vstride, lh * lw * tg);
+            }
+        }
+    }
+    __syncthreads();
+    if (h_key[tid] >= 0) h_base[tid] = atomicAdd(bn.count + (long)h_key[tid] * MSDA_CNT_STRIDE, h_cnt[tid]);
+    __syncthreads();
+    unsigned ovfbits = 0u;          // bit 4 * round + tp: that record did not fit
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int s = j8 + round * 8;
+        if ((code[round][0] | code[round][1] | code[round][2] | code[round][3]) != 0u) {
+            const int l = s / p.P;
+            const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
+            MsdaTap t;
+            msda_tap(loc[s * 2], loc[s * 2 + 1], Hl, Wl, t);
+            const float w = aw[s];
+            float wt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wt[k] = ((k >> 1) ? t.lh : t.hh) * ((k & 1) ? t.lw : t.hw) * w;
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const unsigned cd = code[round][tp];
+                if (cd == 0u) continue;
+                const int slot = (cd & 0x40000000u) ? (int)(cd & 0x3fffffffu) : h_base[(cd >> 16) & 0xffu] + (int)(cd & 0xffffu);
+                if (slot >= bn.cap[l]) { ovfbits |= 1u << (4 * round + tp); continue; }
+                const int cy = t.h0 + (tp >> 1), cx = t.w0 + (tp & 1);
+                const int by0 = cy / MSDA_BS * MSDA_BS, bx0 = cx / MSDA_BS * MSDA_BS;
+                MsdaRec rec;
+                rec.q = q;
+                rec.pos = (unsigned)(t.h0 - by0 + 1) | ((unsigned)(t.w0 - bx0 + 1) << 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = t.h0 + (k >> 1), x = t.w0 + (k & 1);
+                    rec.w[k] = (y >= 0 && y < Hl && x >= 0 && x < Wl) ? wt[k] : 0.f;       // taps outside the level carry nothing
                 }
-                g_a = top * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
-                g_w = (float)Wl * tg * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
-                g_h = (float)Hl * tg * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
+                const long binl = (long)(cy / MSDA_BS) * bn.nbx[l] + cx / MSDA_BS;
+                bn.recs[(long)bm * bn.rtot + bn.roff[l] + binl * bn.cap[l] + slot] = rec;
+            }
+        }
+    }
+    const bool any_ovf = __ballot(ovfbits != 0u) != 0ull;       // wave-uniform: the shuffles below are skipped when nothing overflowed
+    if (!live) return;
+
+    // ---- gather phase: lane = 4 channels ----
+    const int gl0 = (tid & 63) & ~7;           // first lane of this group within the wave
+    const long vstride = (long)p.M * D;
+    const long vbase = (long)b * p.S * vstride + (long)m * D + c4;
+    const float4 top = ldv4(p.grad_out, p.go_f32, grp * D + c4);
+    for (int l = 0; l < p.L; ++l) {
+        const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
+        const long lbase = vbase + p.level_start[l] * vstride;
+        for (int k = 0; k < p.P; ++k) {
+            const int s = l * p.P + k;
+            float g_w = 0.f, g_h = 0.f, g_a = 0.f;
+            MsdaTap t;
+            const bool ok = msda_tap(loc[s * 2], loc[s * 2 + 1], Hl, Wl, t);
+            unsigned o4 = 0u;
+            if (any_ovf) o4 = ((unsigned)__shfl((int)ovfbits, gl0 + (s & 7)) >> (4 * (s >> 3))) & 0xfu;     // owner taps whose bin was full
+            if (ok) {
+                const float w = aw[s];
+                const long r0 = lbase + ((long)t.h0 * Wl + t.w0) * vstride;
+                const long r1 = r0 + (long)Wl * vstride;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v1 = z, v2 = z, v3 = z, v4 = z;
+                if (t.y0ok && t.x0ok) v1 = ldv4(p.value, p.v_f32, r0);
+                if (t.y0ok && t.x1ok) v2 = ldv4(p.value, p.v_f32, r0 + vstride);
+                if (t.y1ok && t.x0ok) v3 = ldv4(p.value, p.v_f32, r1);
+                if (t.y1ok && t.x1ok) v4 = ldv4(p.value, p.v_f32, r1 + vstride);
+                if (o4) {
+                    const int oy1 = (t.y0ok && ((t.h0 + 1) / MSDA_BS) == (t.h0 / MSDA_BS)) ? 0 : 1;     // owner row / column of the second taps
+                    const int ox1 = (t.x0ok && ((t.w0 + 1) / MSDA_BS) == (t.w0 / MSDA_BS)) ? 0 : 1;
+                    const float4 tg = make_float4(top.x * w, top.y * w, top.z * w, top.w * w);
+                    auto scaled = [&](float f) { return make_float4(f * tg.x, f * tg.y, f * tg.z, f * tg.w); };
+                    if (((o4 >> 0) & 1u) && t.y0ok && t.x0ok) atomic_add4(p.grad_value + r0, scaled(t.hh * t.hw));
+                    if (((o4 >> ox1) & 1u) && t.y0ok && t.x1ok) atomic_add4(p.grad_value + r0 + vstride, scaled(t.hh * t.lw));
+                    if (((o4 >> (2 * oy1)) & 1u) && t.y1ok && t.x0ok) atomic_add4(p.grad_value + r1, scaled(t.lh * t.hw));
+                    if (((o4 >> (2 * oy1 + ox1)) & 1u) && t.y1ok && t.x1ok) atomic_add4(p.grad_value + r1 + vstride, scaled(t.lh * t.lw));
+                }
+                const float d1 = dot4(top, v1), d2 = dot4(top, v2), d3 = dot4(top, v3), d4 = dot4(top, v4);
+                g_a = t.hh * t.hw * d1 + t.hh * t.lw * d2 + t.lh * t.hw * d3 + t.lh * t.lw * d4;
+                g_w = (float)Wl * w * (-t.hh * d1 + t.hh * d2 - t.lh * d3 + t.lh * d4);
+                g_h = (float)Hl * w * (-t.hw * d1 - t.lw * d2 + t.hw * d3 + t.lw * d4);
             }
 #pragma unroll
-            for (int o = D / 2; o > 0; o >>= 1) {
+            for (int o = 4; o > 0; o >>= 1) {
                 g_w += __shfl_xor(g_w, o);
                 g_h += __shfl_xor(g_h, o);
                 g_a += __shfl_xor(g_a, o);
             }
-            if (c == 0) {
-                p.grad_loc[(grp * LP + l * p.P + k) * 2] = g_w;
-                p.grad_loc[(grp * LP + l * p.P + k) * 2 + 1] = g_h;
-                p.grad_attn[grp * LP + l * p.P + k] = g_a;
+            if (j8 == 0) {
+                *(float2*)(p.grad_loc + (grp * LP + s) * 2) = make_float2(g_w, g_h);
+                p.grad_attn[grp * LP + s] = g_a;
             }
         }
     }
+}
+
+// pass B: one wave per (bin, slice of its records).  The block's gradient is an outer-product sum
+//   G[pixel][channel] = sum_r W[pixel][r] * T[r][channel],   W = tap weight of record r at the pixel (4 non-zeros per record),
+//                                                            T = grad_out row of the record's query,
+// i.e. a 16 x 32 x (records) GEMM: two v_mfma_f32_16x16x32_bf16 chains (channels 0-15 / 16-31) with K = 32 records per step
+// and the 16 pixels of the block as M.  fp32 operands enter as exact sums of bf16 terms (w = w1 + w2 + w3, 8 + 8 + 8 mantissa
+// bits; a bf16 grad_out is one term already), every partial product is exact in the fp32 accumulator, so the result is an
+// fp32-accumulated sum like the direct kernel's -- without LDS, float atomics or read-modify-write chains in the loop.
+__device__ __forceinline__ bf16 bf16_bits(unsigned u) {
+    const unsigned short h = (unsigned short)(u >> 16);
+    return __builtin_bit_cast(bf16, h);
+}
+// v = t[0] + t[1] + t[2] exactly (truncating splits: each remainder is exactly representable)
+struct Bf3 { bf16 t[3]; };
+__device__ __forceinline__ Bf3 split3(float v) {
+    const unsigned u0 = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(u0);
+    const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(u1);
+    Bf3 o;
+    o.t[0] = bf16_bits(u0); o.t[1] = bf16_bits(u1); o.t[2] = bf16_bits(__float_as_uint(r2));
+    return o;
+}
+
+template <bool GO_F32>
+__global__ __launch_bounds__(256) void msda_bin_reduce_kernel(MsdaP p, MsdaBins bn) {
+    constexpr int D = 32, NT = GO_F32 ? 3 : 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, n16 = lane & 15, g = lane >> 4;
+    const long nitems = (long)p.B * p.M * bn.nwork;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= nitems) return;
+    const int bm = (int)(item / bn.nwork);
+    const int r = (int)(item - (long)bm * bn.nwork);
+    int l = 0;
+    while (l + 1 < p.L && r >= bn.woff[l + 1]) ++l;
+    const int ns = bn.nsplit[l];
+    const int binl = (r - bn.woff[l]) / ns;
+    const int k = (r - bn.woff[l]) - binl * ns;
+    int n = bn.count[((long)bm * bn.nblk + bn.boff[l] + binl) * MSDA_CNT_STRIDE];
+    n = n < bn.cap[l] ? n : bn.cap[l];
+    const int per = (n + ns - 1) / ns;
+    const int lo = k * per;
+    const int cnt = (lo + per < n ? lo + per : n) - lo;
+    if (cnt <= 0) return;
+    const int b = bm / p.M, m = bm - b * p.M;
+    const MsdaRec* recs = bn.recs + (long)bm * bn.rtot + bn.roff[l] + (long)binl * bn.cap[l] + lo;
+    const long gobase = (long)b * p.Lq * p.M * D + (long)m * D + n16;
+    const long gostride = (long)p.M * D;
+    const int py = n16 >> 2, px = n16 & 3;                 // this lane's pixel (row of the W operand)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < cnt; i0 += 32) {
+        bf16x8 wa[3], t0[NT], t1[NT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = i0 + 8 * g + j;
+            int2 hd = make_int2(0, 0);
+            float2 wlo = make_float2(0.f, 0.f), whi = make_float2(0.f, 0.f);
+            if (idx < cnt) {
+                const int2* rp = (const int2*)(recs + idx);
+                hd = rp[0];
+                wlo = *(const float2*)(rp + 1);
+                whi = *(const float2*)(rp + 2);
+            }
+            const int dy = py - ((hd.y & 0xff) - 1), dx = px - (((hd.y >> 8) & 0xff) - 1);
+            float wv = dx ? (dy ? whi.y : wlo.y) : (dy ? whi.x : wlo.x);
+            if ((unsigned)dy > 1u || (unsigned)dx > 1u) wv = 0.f;
+            { const Bf3 ws = split3(wv); wa[0][j] = ws.t[0]; wa[1][j] = ws.t[1]; wa[2][j] = ws.t[2]; }
+            const long gi = gobase + (long)hd.x * gostride;
+            if (GO_F32) {
+                const float* go = (const float*)p.grad_out;
+                const Bf3 s0 = split3(go[gi]), s1 = split3(go[gi + 16]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) { t0[c][j] = s0.t[c]; t1[c][j] = s1.t[c]; }
+            } else {
+                const bf16* go = (const bf16*)p.grad_out;
+                t0[0][j] = go[gi];
+                t1[0][j] = go[gi + 16];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                if (a + c <= 2) {                          // terms below 2^-24 of the product are dropped
+                    acc0 = mfma16(wa[a], t0[c], acc0);
+                    acc1 = mfma16(wa[a], t1[c], acc1);
+                }
+    }
+    // acc: lane holds pixels 4g .. 4g+3 (register index) of channel n16 (acc0) and n16 + 16 (acc1)
+    const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
+    const int by0 = (binl / bn.nbx[l]) * MSDA_BS, bx0 = (binl % bn.nbx[l]) * MSDA_BS;
+    const long vstride = (long)p.M * D;
+    const long lbase = (long)b * p.S * vstride + (long)m * D + n16 + p.level_start[l] * vstride;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int y = by0 + g, x = bx0 + rr;               // pixel 4g + rr = (row g, column rr)
+        if (y < Hl && x < Wl) {
+            float* gp = p.grad_value + lbase + ((long)y * Wl + x) * vstride;
+            if (acc0[rr] != 0.f) atomicAdd(gp, acc0[rr]);
+            if (acc1[rr] != 0.f) atomicAdd(gp + 16, acc1[rr]);
+        }
+    }
+}
+
+// Bin geometry: per level, capacity = 2 x the record count of evenly spread samples (incl. the copies of block-straddling
+// samples, (1 + 1/4)^2 per sample), at least 64; pass-B slices per bin so that a wave sums ~384 records.
+static int msda_plan_bins(const int64_t* shapes_host, int L, int Lq, int P, int D, MsdaBins& bn) {
+    if (L > MSDA_TL || D != 32 || L * P > 16) return 0;
+    int off = 0, woff = 0;
+    long roff = 0;
+    for (int l = 0; l < MSDA_TL; ++l) {
+        bn.nbx[l] = 1; bn.boff[l] = off; bn.cap[l] = 0; bn.roff[l] = roff; bn.nsplit[l] = 1; bn.woff[l] = woff;
+        if (l >= L) continue;
+        const long Hl = shapes_host[2 * l], Wl = shapes_host[2 * l + 1];
+        if (Hl <= 0 || Wl <= 0) return 0;
+        const long nby = (Hl + MSDA_BS - 1) / MSDA_BS, nbx = (Wl + MSDA_BS - 1) / MSDA_BS;
+        const double expect = (double)Lq * P / (double)(nby * nbx) * 1.5625;
+        long cap = (long)(2.0 * expect) + 1;
+        cap = cap < 64 ? 64 : (cap + 31) / 32 * 32;
+        if (cap > 0xffff0) return 0;
+        long ns = (long)(expect / 384.0 + 0.5);
+        ns = ns < 1 ? 1 : (ns > 64 ? 64 : ns);
+        bn.nbx[l] = (int)nbx; bn.cap[l] = (int)cap; bn.nsplit[l] = (int)ns;
+        off += (int)(nby * nbx);
+        woff += (int)(nby * nbx * ns);
+        roff += nby * nbx * cap;
+    }
+    bn.nblk = off;
+    bn.nwork = woff;
+    bn.rtot = roff;
+    return 1;
 }
 
 static int msda_fill(MsdaP& p, const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
@@ -176,18 +521,49 @@ extern "C" int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int6
     UENC_LAUNCH_RET();
 }
 
+// Bytes of scratch the binned backward needs (0: shape not eligible, the direct kernel runs and needs none).
+extern "C" long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, int M, int D, int L, int Lq, int P) {
+    MsdaBins bn;
+    if (!shapes_host || B <= 0 || M <= 0 || !msda_plan_bins(shapes_host, L, Lq, P, D, bn)) return 0;
+    const long nbins = (long)B * M * bn.nblk;
+    return nbins * MSDA_CNT_STRIDE * 4 + (long)B * M * bn.rtot * (long)sizeof(MsdaRec);
+}
+
 // Mirrors ms_deform_attn_backward(...): grad_value must be zero-filled by the caller (it is accumulated);
-// grad_loc / grad_attn are fully overwritten.
+// grad_loc / grad_attn are fully overwritten.  With shapes_host (host copy of `shapes`) and a workspace of
+// uenc_msdeform_attn_bwd_workspace_bytes() bytes the binned kernels run, else the direct-atomics one.
 extern "C" int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
                                       const float* loc, const float* attn, const void* grad_out, int go_dtype,
                                       float* grad_value, float* grad_loc, float* grad_attn, int B, int S, int M, int D, int L,
-                                      int Lq, int P, hipStream_t stream) {
+                                      int Lq, int P, const int64_t* shapes_host, void* workspace, long workspace_bytes,
+                                      hipStream_t stream) {
     MsdaP p;
     int rc = msda_fill(p, value, v_dtype, shapes, level_start, loc, attn, B, S, M, D, L, Lq, P);
     if (rc != UENC_OK) return rc;
     UENC_CHECK_ARG(grad_out && grad_value && grad_loc && grad_attn && (D == 32 || D == 64 || D == 16));
+    UENC_CHECK_ARG(((uintptr_t)grad_out & 15) == 0);
     p.grad_out = grad_out; p.go_f32 = (go_dtype == UENC_F32);
     p.grad_value = grad_value; p.grad_loc = grad_loc; p.grad_attn = grad_attn;
+    MsdaBins bn;
+    if (shapes_host != nullptr && workspace != nullptr && msda_plan_bins(shapes_host, L, Lq, P, D, bn)) {
+        long tot = 0;
+        for (int l = 0; l < L; ++l) tot += shapes_host[2 * l] * shapes_host[2 * l + 1];
+        const long nbins = (long)B * M * bn.nblk;
+        const long cnt_bytes = nbins * MSDA_CNT_STRIDE * 4;
+        const long nchunk = (Lq + 31) / 32;
+        UENC_CHECK_ARG(tot == S && ((uintptr_t)workspace & 15) == 0 &&
+                       workspace_bytes >= cnt_bytes + (long)B * M * bn.rtot * (long)sizeof(MsdaRec));
+        const long nitems = (long)B * M * bn.nwork;
+        UENC_CHECK_ARG(nbins < (1L << 31) && nchunk * B * M < (1L << 31) && (nitems + 3) / 4 < (1L << 31));
+        bn.count = (int*)workspace;
+        bn.recs = (MsdaRec*)((char*)workspace + cnt_bytes);
+        hipError_t e = hipMemsetAsync(bn.count, 0, (size_t)cnt_bytes, stream);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(msda_bwd_bin_kernel, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
+        if (p.go_f32) hipLaunchKernelGGL(msda_bin_reduce_kernel<true>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
+        else hipLaunchKernelGGL(msda_bin_reduce_kernel<false>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
+        UENC_LAUNCH_RET();
+    }
     const long threads = (long)B * Lq * M * D;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     if (D == 32) hipLaunchKernelGGL(msda_bwd_kernel<32>, dim3(grid), dim3(256), 0, stream, p);

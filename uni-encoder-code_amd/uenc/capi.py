@@ -32,7 +32,8 @@ _SIGNATURES = {
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p],
     "uenc_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p],
     "uenc_msdeform_attn_fwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
-    "uenc_msdeform_attn_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_msdeform_attn_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p],
+    "uenc_msdeform_attn_bwd_workspace_bytes": [c_p, c_i, c_i, c_i, c_i, c_i, c_i],
     "uenc_mha_fwd_workspace_floats": [c_i, c_i, c_i, c_i],
     "uenc_mha_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_mha_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
@@ -61,6 +62,7 @@ def _load():
         fn.restype = c_i
     lib.uenc_window_attn_bwd_ws_rows.restype = c_l
     lib.uenc_mha_fwd_workspace_floats.restype = c_l
+    lib.uenc_msdeform_attn_bwd_workspace_bytes.restype = c_l
     lib.uenc_arch.restype = ctypes.c_char_p
     lib.uenc_arch.argtypes = []
     return lib

@@ -183,17 +183,41 @@ def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.flo
     return out
 
 
-def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out):
-    """-> grad_value (fp32, B,S,M,D), grad_loc, grad_attn (the reference's ms_deform_attn_backward contract)."""
+_MSDA_WS = {}
+
+
+def _msda_workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch for the binned backward (bin counters + records), kept across calls: one buffer per device, grown on demand."""
+    buf = _MSDA_WS.get(str(device))
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _MSDA_WS[str(device)] = buf
+    return buf
+
+
+def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out, shapes_host=None):
+    """-> grad_value (fp32, B,S,M,D), grad_loc, grad_attn (the reference's ms_deform_attn_backward contract).
+
+    shapes_host: optional [(H, W), ...] host copy of `shapes`; enables the binned (on-chip summed) grad_value path."""
     B, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     assert grad_out.is_contiguous() and grad_out.shape == (B, Lq, M * D)
     gv = torch.zeros((B, S, M, D), dtype=torch.float32, device=value.device)
     gl = torch.empty_like(loc)
     ga = torch.empty_like(attn)
+    sh, ws, ws_bytes = None, None, 0
+    if shapes_host is not None:
+        import ctypes
+        flat = [int(v) for hw in shapes_host for v in hw]
+        assert len(flat) == 2 * L
+        sh = (ctypes.c_int64 * len(flat))(*flat)
+        ws_bytes = int(lib.uenc_msdeform_attn_bwd_workspace_bytes(sh, B, M, D, L, Lq, P))
+        if ws_bytes > 0:
+            ws = _msda_workspace(ws_bytes, value.device)
     check(lib.uenc_msdeform_attn_bwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(),
                                      attn.data_ptr(), grad_out.data_ptr(), dt(grad_out), gv.data_ptr(), gl.data_ptr(),
-                                     ga.data_ptr(), B, S, M, D, L, Lq, P, stream_ptr()), "msdeform_attn_bwd")
+                                     ga.data_ptr(), B, S, M, D, L, Lq, P, sh, ws.data_ptr() if ws is not None else None,
+                                     ws_bytes, stream_ptr()), "msdeform_attn_bwd")
     return gv, gl, ga
 
 
@@ -201,7 +225,7 @@ def attn_mask(logits: torch.Tensor, size) -> torch.Tensor:
     """(B, Q, Hi, Wi) fp32 mask logits -> (B, Q, Ho*Wo) bool, True = blocked; fully blocked rows are cleared."""
     B, Q, Hi, Wi = logits.shape
     Ho, Wo = int(size[0]), int(size[1])
-    assert logits.dtype == torch.float32 and logits.is_cuda and logits.is_contiguous() and Wo % 4 == 0
+    assert logits.dtype == torch.float32 and logits.is_cuda and logits.is_contiguous()
     out = torch.empty((B, Q, Ho * Wo), dtype=torch.bool, device=logits.device)
     check(lib.uenc_attn_mask(logits.data_ptr(), out.data_ptr(), B * Q, Hi, Wi, Ho, Wo, stream_ptr()), "attn_mask")
     return out

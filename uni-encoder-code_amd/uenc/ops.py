@@ -423,6 +423,22 @@ def swin_block(x, H, W, ws, shift, nH, scale, params: Sequence[torch.Tensor]):
 # --------------------------------------------------------------------------------------------
 # multi-scale deformable attention core (the reference's MSDeformAttnFunction, same argument order)
 # --------------------------------------------------------------------------------------------
+_HOST_SHAPES = {}
+
+
+def _host_shapes(shapes: torch.Tensor):
+    """Host copy of a (L, 2) spatial-shapes tensor; one device sync per distinct tensor object (the pixel decoder keeps
+    its geometry tensors alive across steps), none afterwards."""
+    ent = _HOST_SHAPES.get(id(shapes))
+    if ent is not None and ent[0]() is shapes and ent[1] == shapes._version:
+        return ent[2]
+    if len(_HOST_SHAPES) > 64:
+        _HOST_SHAPES.clear()
+    host = [tuple(int(v) for v in hw) for hw in shapes.tolist()]
+    _HOST_SHAPES[id(shapes)] = (weakref.ref(shapes), shapes._version, host)
+    return host
+
+
 class MSDeformAttnFunction(torch.autograd.Function):
     """pixel_decoder/ops/functions/ms_deform_attn_func.py:35-52: forward(value, spatial_shapes,
     level_start_index, sampling_locations, attention_weights, im2col_step) -> (N, Lq, M*D)."""
@@ -438,12 +454,13 @@ class MSDeformAttnFunction(torch.autograd.Function):
         out = K.msdeform_attn_fwd(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                                   attention_weights, out_dtype=out_dtype or (F32 if value.dtype == F32 else BF16))
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        ctx.shapes_host = _host_shapes(value_spatial_shapes)        # lets the backward bin grad_value per block of pixels
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
         value, shapes, start, loc, attn = ctx.saved_tensors
-        gv, gl, ga = K.msdeform_attn_bwd(value, shapes, start, loc, attn, grad_output.contiguous())
+        gv, gl, ga = K.msdeform_attn_bwd(value, shapes, start, loc, attn, grad_output.contiguous(), ctx.shapes_host)
         return (gv if value.dtype == F32 else gv.to(value.dtype)), None, None, gl, ga, None, None
 
 
