@@ -97,13 +97,13 @@ int uenc_relpos_expand(const float* table /* ((2ws-1)^2, nH) */, float* bias_q /
                        float* bias_k /* (nH,NP,NP) [h][key][q] */, int nH, int ws, void* stream);
 int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
                          int C, int nH, int ws, int shift, float scale, void* stream);
-/* dqkv (B,H,W,3C) bf16 written.  dtab_ws: (uenc_window_attn_bwd_ws_rows(...), (2ws-1)^2 + 96) fp32 scratch, fully
- * overwritten: row (window * nH + head) = that workgroup's partial relative-position-table gradient followed by the
- * [3][32] (q|k|v) slice of the qkv.bias gradient reaching that head through padding slots; the caller sums rows over
- * windows (no global atomics: results are bitwise reproducible). */
-long uenc_window_attn_bwd_ws_rows(int B, int H, int W, int nH, int ws);
+/* dqkv (B,H,W,3C) bf16 written.  dS_ws: scratch of uenc_window_attn_bwd_ws_floats() floats (dense per-workgroup sums of
+ * dS, overwritten).  dgrads: (nH * (2ws-1)^2 + 3C) fp32, overwritten: the relative-position-table gradient as
+ * [head][(2ws-1)^2], then the q | k | v slice of the qkv.bias gradient that flows through padding slots (the zero rows
+ * F.pad appends after norm1, swin.py:254, whose q/k/v equal the bias). */
+long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws);
 int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                         const void* o_saved, const void* d_out, void* dqkv, float* dtab_ws, int B,
+                         const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dgrads, int B,
                          int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
 
 /* ---- multi-scale deformable attention: the reference's native op ---------------------------------------

@@ -41,8 +41,8 @@ struct WAttn {
     const bf16* o_saved;    // forward output
     const bf16* d_out;      // (B, H, W, C)
     bf16* dqkv;             // (B, H, W, 3C)
-    float* dtab_ws;         // (nWinTotal * nH, (2ws-1)^2 + 96) per-workgroup partials (overwritten): table gradient, then
-                            // the q|k|v (3 x 32) qkv-bias gradient that reaches this head through padding slots
+    float* dtab_ws;         // (nH * G, NP * NP) dense dS partial per workgroup (overwritten)
+    float* dpad;            // (3C) q|k|v bias gradient that reaches the heads through padding slots (zeroed by the launcher, atomics)
     int B, H, W, C, nH, ws, shift, Hp, Wp, nWw, nWin, nWinTotal, N;
     float scale;
 };
@@ -218,237 +218,333 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// Persistent: the grid is nH x G workgroups, workgroup (head, g) walks windows g, g + G, ... of its head.
+//   * the q/k/v/dO rows of the NEXT window go global -> LDS by LDS-DMA (global_load_lds_dwordx4, lane-linear destination,
+//     XOR swizzle applied to the per-lane source chunk) into the second of two stages while the current window is
+//     computed; its saved forward output rows (for delta) are prefetched into registers;
+//   * the relative-position-table gradient is NOT scattered per window (LDS float atomics cost ~3 cycles per lane:
+//     20k of them per window-head were two thirds of this kernel): dS is the same accumulator tile for every window, so
+//     it is summed over the workgroup's windows in registers and written once as a dense [q][key] partial;
+//     wattn_dtable_kernel then sums the partials over g and along the diagonals (q - key = const) into the table gradient.
+__device__ __attribute__((aligned(16))) unsigned int g_wattn_zero16[4];      // a 16-byte chunk of zeros (rows beyond N, dO pad rows)
+
 template <int NTILES>
-__global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p) {
+__global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) {
     using Cf = WCfg<NTILES>;
     constexpr int NTH = Cf::NTH, NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
-    constexpr int OFF_TOK = 4 * NK2 * 64;
-    constexpr int OFF_LSE = OFF_TOK + NK2 * 4;
+    constexpr int IMG = NK2 * 64, STAGE = 4 * IMG;
+    constexpr int OFF_TOK = 2 * STAGE;                 // int tokoff[2][NK2]
+    constexpr int OFF_RID = OFF_TOK + 2 * NK2 * 4;     // u8  rid[2][NK2]
+    constexpr int OFF_LSE = OFF_RID + 2 * NK2;         // float lse[NK2], delta[NK2]
     constexpr int OFF_DEL = OFF_LSE + NK2 * 4;
-    constexpr int OFF_YX = OFF_DEL + NK2 * 4;
-    constexpr int OFF_RID = OFF_YX + NK2 * 2;
-    constexpr int OFF_TAB = (OFF_RID + NK2 + 15) / 16 * 16;
+    constexpr int OFF_PAD = OFF_DEL + NK2 * 4;         // float padacc[96]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Qs = smem;
-    unsigned char* Ks = smem + NK2 * 64;
-    unsigned char* Vs = smem + 2 * NK2 * 64;
-    unsigned char* dOs = smem + 3 * NK2 * 64;
-    int* tokoff = (int*)(smem + OFF_TOK);
     float* lse = (float*)(smem + OFF_LSE);
     float* delta = (float*)(smem + OFF_DEL);
-    unsigned short* yx = (unsigned short*)(smem + OFF_YX);
-    unsigned char* rid = smem + OFF_RID;
-    float* tab = (float*)(smem + OFF_TAB);          // 4 replicas (one per lane group fg): conflict-free ds_add
-    const int T1 = 2 * p.ws - 1, TT = T1 * T1;
-    float* padacc = tab + 4 * TT;                   // [3][32] q|k|v bias gradient from padding slots
+    float* padacc = (float*)(smem + OFF_PAD);          // [3][32] q|k|v bias gradient from padding slots, summed over this WG's windows
 
-    int win, head;
-    decode_block(p, win, head);
-    if (win >= p.nWinTotal) return;
-    const int b = win / p.nWin, wrem = win - b * p.nWin;
-    const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    // block -> (head, g): heads 2i / 2i+1 (the two halves of a 128-byte line of q, k, v, dO) on the same XCD
+    int head, g;
+    {
+        const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int U = (idx >> 1) * 8 + x, npair = (p.nH + 1) >> 1;
+        head = 2 * (U % npair) + (idx & 1);
+        g = U / npair;
+    }
+    if (head >= p.nH || g >= G) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fg = lane >> 4;
     const int C = p.C, hoff = head * 32;
     const long C3 = 3 * (long)p.C;
-
-    float4 bq[NTILES];       // bias_q row segment of this lane's query (phase A), later bias_k of its key (phase B)
-    {
-        const float* brow0 = p.bias_q + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
-#pragma unroll
-        for (int kt = 0; kt < NTILES; ++kt) bq[kt] = *(const float4*)(brow0 + kt * 16);
-    }
-    window_slots<NK2>(p, b, wi, wj, tokoff, rid, yx, NTH);
-    for (int t = threadIdx.x; t < 4 * TT + 96; t += NTH) tab[t] = 0.f;
-    __syncthreads();
-    {
-        unsigned char* const img[4] = {Qs, Ks, Vs, dOs};
-        const bf16* const base[4] = {p.qkv + hoff, p.qkv + C + hoff, p.qkv + 2 * C + hoff, p.d_out + hoff};
-        const long stride[4] = {C3, C3, C3, (long)C};
-        const bf16* const pad[4] = {p.qkv_bias + hoff, p.qkv_bias + C + hoff, p.qkv_bias + 2 * C + hoff, nullptr};
-        stage_images<4, NK2, NTH>(img, base, stride, pad, tokoff);
-    }
-    __syncthreads();
-
-    const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
     const float sc = p.scale * LOG2E;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) void lds_void;
 
-    // ---------------- phase A: this wave's 16 queries x all keys (key-major S^T): statistics, dTable, dQ ----------------
+    auto slots = [&](int win, int st) {
+        const int b = win / p.nWin, wrem = win - b * p.nWin;
+        const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
+        window_slots<NK2>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
+    };
+    // LDS-DMA of one window's q, k, v, dO images: 16 rows (1 KB) per wave instruction
+    auto issue = [&](int st) {
+        const int* tok = (const int*)(smem + OFF_TOK) + st * NK2;
+        constexpr int PER_IMG = NK2 / 16;
+        for (int ii = wave; ii < 4 * PER_IMG; ii += NTILES) {
+            const int img = ii / PER_IMG, rb = ii - img * PER_IMG;
+            const int row = rb * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
+            const int t = tok[row];
+            const bf16* src = (const bf16*)g_wattn_zero16;
+            if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : p.d_out + (long)t * C) + hoff + chunk * 8;
+            else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
+            __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 dsacc[NTILES];
+#pragma unroll
+    for (int kt = 0; kt < NTILES; ++kt) dsacc[kt] = zero4;
+    for (int t = threadIdx.x; t < 96; t += NTH) padacc[t] = 0.f;
+
+    int win = g;
+    bf16x8 o_next;                                     // saved forward output row of this lane's query, next window
     {
-        const int qt = wave, qi = qt * 16 + fr;
-        const int qtok = tokoff[qi];
-        const bf16x8 qf = frag_rows(Qs, qt * 16, fr, fg);
-        const bf16x8 dof = frag_rows(dOs, qt * 16, fr, fg);
-        float dl = 0.f;                               // delta[q] = sum_d dO[q][d] * O[q][d]
-        if (qtok >= 0) {
-            const bf16x8 ov = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dl += (float)ov[j] * (float)dof[j];
-        }
-        dl += __shfl_xor(dl, 16);
-        dl += __shfl_xor(dl, 32);
-        f32x4 s[NTILES];
-        const int ridq = rid[qi];
-        float mx = -1e30f;
-#pragma unroll
-        for (int kt = 0; kt < NTILES; ++kt) {
-            s[kt] = mfma16(frag_rows(Ks, kt * 16, fr, fg), qf, zero4);
-            const float4 bb = bq[kt];
-            s[kt][0] = s[kt][0] * sc + bb.x; s[kt][1] = s[kt][1] * sc + bb.y;
-            s[kt][2] = s[kt][2] * sc + bb.z; s[kt][3] = s[kt][3] * sc + bb.w;
-            if (masked) {
-                const unsigned rk = *(const unsigned*)(rid + kt * 16 + 4 * fg);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if ((int)((rk >> (8 * r)) & 0xffu) != ridq) s[kt][r] -= 100.0f * LOG2E;
-            }
-            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);     // bound the loads hoisted ahead (register pressure)
-        }
-        {   // bias_q is consumed: start fetching the key-major bias of phase B (this wave's key tile) into the same registers
-            const float* bcol0 = p.bias_k + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
-#pragma unroll
-            for (int qt2 = 0; qt2 < NTILES; ++qt2) bq[qt2] = *(const float4*)(bcol0 + qt2 * 16);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NTILES; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[kt][r] - mx);
-                s[kt][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-        if (fg == 0) { lse[qi] = mx + log2f(sum); delta[qi] = dl; }     // log2-domain log-sum-exp
-        __builtin_amdgcn_sched_barrier(0);
-        const int qcode = yx[qi];
-        const int qy = qcode >> 8, qx = qcode & 0xff;
-        const bool qreal = qi < p.N;
-#pragma unroll
-        for (int kt = 0; kt < NTILES; ++kt) {
-            const f32x4 dp = mfma16(frag_rows(Vs, kt * 16, fr, fg), dof, zero4);     // dP^T[key][q] = V[key] . dO[q]
-            const uint2 kc = *(const uint2*)(yx + kt * 16 + 4 * fg);
-            const unsigned kcs[4] = {kc.x & 0xffffu, kc.x >> 16, kc.y & 0xffffu, kc.y >> 16};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ds = s[kt][r] * inv * (dp[r] - dl);
-                s[kt][r] = ds;
-                const int key = kt * 16 + 4 * fg + r;
-                if (qreal && key < p.N) {
-                    const int ky = kcs[r] >> 8, kx = kcs[r] & 0xff;
-                    atomicAdd(&tab[fg * TT + (qy - ky + p.ws - 1) * T1 + (qx - kx + p.ws - 1)], ds);
-                }
-            }
-            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 dq[2] = {zero4, zero4};                  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            bf16x8 pb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pb[r] = (bf16)s[2 * kb][r];
-                pb[4 + r] = (2 * kb + 1 < NTILES) ? (bf16)s[(2 * kb + 1 < NTILES) ? 2 * kb + 1 : 0][r] : (bf16)0.f;
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma16(frag_tr(Ks, 32 * kb, 32 * kb + 16, dt * 16, lane), pb, dq[dt]);
-        }
-        if (qtok != -2) {
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int col = hoff + dt * 16 + 4 * fg;
-                if (qtok >= 0) {
-                    bf16x4 ov;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = (bf16)(dq[dt][r] * p.scale);
-                    *(bf16x4*)(p.dqkv + (long)qtok * C3 + col) = ov;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(padacc + dt * 16 + 4 * fg + r, dq[dt][r] * p.scale);
-                }
-            }
-        }
+        for (int j = 0; j < 8; ++j) o_next[j] = (bf16)0.f;
     }
-    __syncthreads();   // lse / delta / tab complete
+    if (win < p.nWinTotal) {
+        slots(win, 0);
+        __syncthreads();
+        issue(0);
+        const int qtok = ((const int*)(smem + OFF_TOK))[wave * 16 + fr];
+        if (qtok >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
+    }
+    for (int it = 0; win < p.nWinTotal; ++it, win += G) {
+        const int st = it & 1;
+        const unsigned char* Qs = smem + st * STAGE;
+        const unsigned char* Ks = Qs + IMG;
+        const unsigned char* Vs = Qs + 2 * IMG;
+        const unsigned char* dOs = Qs + 3 * IMG;
+        const int* tokoff = (const int*)(smem + OFF_TOK) + st * NK2;
+        const unsigned char* rid = smem + OFF_RID + st * NK2;
+        const int b = win / p.nWin, wrem = win - b * p.nWin;
+        const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
+        const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
+        const bool more = win + G < p.nWinTotal;
 
-    // ---------------- phase B: this wave's 16 keys x all queries (query-major S): dK, dV ----------------
-    {
-        const int kt = wave, ki = kt * 16 + fr;
-        const int ktok = tokoff[ki];
-        const bf16x8 kfB = frag_rows(Ks, kt * 16, fr, fg);
-        const bf16x8 vfB = frag_rows(Vs, kt * 16, fr, fg);
-        const int ridk = rid[ki];
-        f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+        // bias rows come from L2 in groups of 3 key tiles (phase A) / 2 query tiles (phase B), one group ahead of their use
+        // (all NTILES at once would be 36 more live registers than the 168 a 9-wave workgroup can have)
+        const float* brow0 = p.bias_q + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
+        const float* bcol0 = p.bias_k + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
+        float4 bnext[3];
 #pragma unroll
-        for (int qb = 0; qb < NKB; ++qb) {
-            f32x4 pt[2], dst[2];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int qt = 2 * qb + h2;
-                if (qt < NTILES) {
-                    const f32x4 sv = mfma16(frag_rows(Qs, qt * 16, fr, fg), kfB, zero4);    // S[q = 4fg+r][key = fr]
-                    const f32x4 dp = mfma16(frag_rows(dOs, qt * 16, fr, fg), vfB, zero4);
-                    const float4 bb = bq[qt < NTILES ? qt : 0];
-                    const float4 l4 = *(const float4*)(lse + qt * 16 + 4 * fg);
-                    const float4 d4 = *(const float4*)(delta + qt * 16 + 4 * fg);
-                    const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w};
-                    const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-                    unsigned rq = 0;
-                    if (masked) rq = *(const unsigned*)(rid + qt * 16 + 4 * fg);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = sv[r] * sc + bv[r];
-                        if (masked && (int)((rq >> (8 * r)) & 0xffu) != ridk) v -= 100.0f * LOG2E;
-                        const float pr = exp2f(v - lv[r]);
-                        pt[h2][r] = pr;
-                        dst[h2][r] = pr * (dp[r] - dv4[r]);
-                    }
-                } else {
-                    pt[h2] = zero4; dst[h2] = zero4;
-                }
-            }
-            bf16x8 pb, db;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pb[r] = (bf16)pt[0][r]; pb[4 + r] = (bf16)pt[1][r];
-                db[r] = (bf16)dst[0][r]; db[4 + r] = (bf16)dst[1][r];
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = mfma16(frag_tr(dOs, 32 * qb, 32 * qb + 16, dt * 16, lane), pb, dv[dt]);   // dV^T += dO^T P
-                dk[dt] = mfma16(frag_tr(Qs, 32 * qb, 32 * qb + 16, dt * 16, lane), db, dk[dt]);    // dK^T += Q^T dS
-            }
+        for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
+        const bf16x8 ov = o_next;
+        if (more) slots(win + G, st ^ 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): this wave's share of the current stage has landed (and bq)
+        __syncthreads();                               // ... everyone's; next window's slots are visible
+        if (more) {
+            issue(st ^ 1);
+            const int qtok_n = ((const int*)(smem + OFF_TOK))[(st ^ 1) * NK2 + wave * 16 + fr];
+            if (qtok_n >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok_n * C + hoff + 8 * fg);
         }
-        if (ktok != -2) {
+
+        // ---------------- phase A: this wave's 16 queries x all keys (key-major S^T): statistics, dS, dQ ----------------
+        {
+            const int qt = wave, qi = qt * 16 + fr;
+            const int qtok = tokoff[qi];
+            const bf16x8 qf = frag_rows(Qs, qt * 16, fr, fg);
+            const bf16x8 dof = frag_rows(dOs, qt * 16, fr, fg);
+            float dl = 0.f;                               // delta[q] = sum_d dO[q][d] * O[q][d]
+            if (qtok >= 0) {
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int col = hoff + dt * 16 + 4 * fg;
-                if (ktok >= 0) {
-                    bf16x4 kv, vv;
+                for (int j = 0; j < 8; ++j) dl += (float)ov[j] * (float)dof[j];
+            }
+            dl += __shfl_xor(dl, 16);
+            dl += __shfl_xor(dl, 32);
+            f32x4 s[NTILES];
+            const int ridq = rid[qi];
+            float mx = -1e30f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { kv[r] = (bf16)(dk[dt][r] * p.scale); vv[r] = (bf16)dv[dt][r]; }
-                    *(bf16x4*)(p.dqkv + (long)ktok * C3 + C + col) = kv;
-                    *(bf16x4*)(p.dqkv + (long)ktok * C3 + 2 * C + col) = vv;
-                } else {
+            for (int k3 = 0; k3 < NTILES; k3 += 3) {
+                float4 bcur[3];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        atomicAdd(padacc + 32 + dt * 16 + 4 * fg + r, dk[dt][r] * p.scale);
-                        atomicAdd(padacc + 64 + dt * 16 + 4 * fg + r, dv[dt][r]);
+                for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
+                if (k3 + 3 < NTILES) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (k3 + 3 + j < NTILES ? k3 + 3 + j : 0) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int kt = k3 + j;
+                    if (kt < NTILES) {
+                        s[kt] = mfma16(frag_rows(Ks, kt * 16, fr, fg), qf, zero4);
+                        const float4 bb = bcur[j];
+                        s[kt][0] = s[kt][0] * sc + bb.x; s[kt][1] = s[kt][1] * sc + bb.y;
+                        s[kt][2] = s[kt][2] * sc + bb.z; s[kt][3] = s[kt][3] * sc + bb.w;
+                        if (masked) {
+                            const unsigned rk = *(const unsigned*)(rid + kt * 16 + 4 * fg);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if ((int)((rk >> (8 * r)) & 0xffu) != ridq) s[kt][r] -= 100.0f * LOG2E;
+                        }
+                        mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);     // bound the loads hoisted ahead (register pressure)
+            }
+            // first two query tiles of the key-major bias for phase B
+            bnext[0] = *(const float4*)bcol0;
+            bnext[1] = *(const float4*)(bcol0 + (1 < NTILES ? 16 : 0));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NTILES; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[kt][r] - mx);
+                    s[kt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            if (fg == 0) { lse[qi] = mx + log2f(sum); delta[qi] = dl; }     // log2-domain log-sum-exp
+            __builtin_amdgcn_sched_barrier(0);
+            const bool qreal = qi < p.N;
+#pragma unroll
+            for (int kt = 0; kt < NTILES; ++kt) {
+                const f32x4 dp = mfma16(frag_rows(Vs, kt * 16, fr, fg), dof, zero4);     // dP^T[key][q] = V[key] . dO[q]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ds = s[kt][r] * inv * (dp[r] - dl);
+                    s[kt][r] = ds;
+                    if (qreal) dsacc[kt][r] += ds;          // keys >= N have P = 0 exactly
+                }
+                if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 dq[2] = {zero4, zero4};                  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                bf16x8 pb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pb[r] = (bf16)s[2 * kb][r];
+                    pb[4 + r] = (2 * kb + 1 < NTILES) ? (bf16)s[(2 * kb + 1 < NTILES) ? 2 * kb + 1 : 0][r] : (bf16)0.f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma16(frag_tr(Ks, 32 * kb, 32 * kb + 16, dt * 16, lane), pb, dq[dt]);
+            }
+            if (qtok != -2) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int col = hoff + dt * 16 + 4 * fg;
+                    if (qtok >= 0) {
+                        bf16x4 o4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o4[r] = (bf16)(dq[dt][r] * p.scale);
+                        *(bf16x4*)(p.dqkv + (long)qtok * C3 + col) = o4;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(padacc + dt * 16 + 4 * fg + r, dq[dt][r] * p.scale);
+                    }
+                }
             }
         }
+        __syncthreads();   // lse / delta complete
+
+        // ---------------- phase B: this wave's 16 keys x all queries (query-major S): dK, dV ----------------
+        {
+            const int kt = wave, ki = kt * 16 + fr;
+            const int ktok = tokoff[ki];
+            const bf16x8 kfB = frag_rows(Ks, kt * 16, fr, fg);
+            const bf16x8 vfB = frag_rows(Vs, kt * 16, fr, fg);
+            const int ridk = rid[ki];
+            f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+#pragma unroll
+            for (int qb = 0; qb < NKB; ++qb) {
+                f32x4 pt[2], dst[2];
+                const float4 bcur[2] = {bnext[0], bnext[1]};
+                if (qb + 1 < NKB) {
+                    bnext[0] = *(const float4*)(bcol0 + (2 * qb + 2) * 16);
+                    bnext[1] = *(const float4*)(bcol0 + (2 * qb + 3 < NTILES ? 2 * qb + 3 : 0) * 16);
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int qt = 2 * qb + h2;
+                    if (qt < NTILES) {
+                        const f32x4 sv = mfma16(frag_rows(Qs, qt * 16, fr, fg), kfB, zero4);    // S[q = 4fg+r][key = fr]
+                        const f32x4 dp = mfma16(frag_rows(dOs, qt * 16, fr, fg), vfB, zero4);
+                        const float4 bb = bcur[h2];
+                        const float4 l4 = *(const float4*)(lse + qt * 16 + 4 * fg);
+                        const float4 d4 = *(const float4*)(delta + qt * 16 + 4 * fg);
+                        const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w};
+                        const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+                        unsigned rq = 0;
+                        if (masked) rq = *(const unsigned*)(rid + qt * 16 + 4 * fg);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = sv[r] * sc + bv[r];
+                            if (masked && (int)((rq >> (8 * r)) & 0xffu) != ridk) v -= 100.0f * LOG2E;
+                            const float pr = exp2f(v - lv[r]);
+                            pt[h2][r] = pr;
+                            dst[h2][r] = pr * (dp[r] - dv4[r]);
+                        }
+                    } else {
+                        pt[h2] = zero4; dst[h2] = zero4;
+                    }
+                }
+                bf16x8 pb, db;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pb[r] = (bf16)pt[0][r]; pb[4 + r] = (bf16)pt[1][r];
+                    db[r] = (bf16)dst[0][r]; db[4 + r] = (bf16)dst[1][r];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = mfma16(frag_tr(dOs, 32 * qb, 32 * qb + 16, dt * 16, lane), pb, dv[dt]);   // dV^T += dO^T P
+                    dk[dt] = mfma16(frag_tr(Qs, 32 * qb, 32 * qb + 16, dt * 16, lane), db, dk[dt]);    // dK^T += Q^T dS
+                }
+            }
+            if (ktok != -2) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int col = hoff + dt * 16 + 4 * fg;
+                    if (ktok >= 0) {
+                        bf16x4 kv, vv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { kv[r] = (bf16)(dk[dt][r] * p.scale); vv[r] = (bf16)dv[dt][r]; }
+                        *(bf16x4*)(p.dqkv + (long)ktok * C3 + C + col) = kv;
+                        *(bf16x4*)(p.dqkv + (long)ktok * C3 + 2 * C + col) = vv;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            atomicAdd(padacc + 32 + dt * 16 + 4 * fg + r, dk[dt][r] * p.scale);
+                            atomicAdd(padacc + 64 + dt * 16 + 4 * fg + r, dv[dt][r]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // stage st, lse / delta and tokoff[st] are free for the window after next
+    }
+    // dense dS partial of this workgroup: [wave = query tile][kt][lane][4]  <->  q = 16 wave + (lane & 15), key = 16 kt + 4 (lane >> 4) + r
+    float* wsp = p.dtab_ws + (((long)head * G + g) * NTILES + wave) * (NP * 16);
+#pragma unroll
+    for (int kt = 0; kt < NTILES; ++kt) *(f32x4*)(wsp + (kt * 64 + lane) * 4) = dsacc[kt];
+    for (int t = threadIdx.x; t < 96; t += NTH) {
+        const float v = padacc[t];
+        if (v != 0.f) atomicAdd(p.dpad + (t >> 5) * C + hoff + (t & 31), v);
+    }
+}
+
+// Table gradient from the dense dS partials: one workgroup per (head, query tile) sums the partials of the G groups
+// (coalesced) into LDS, then every table entry (dy, dx) adds up the slab's pairs q - key = (dy, dx).
+template <int NTILES>
+__global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restrict__ wsd, float* __restrict__ dtab, int G, int nH,
+                                                           int ws) {
+    constexpr int NP = NTILES * 16, SLAB = NP * 16;
+    __shared__ __attribute__((aligned(16))) float slab[SLAB];
+    const int head = blockIdx.x / NTILES, qt = blockIdx.x - head * NTILES;
+    for (int e = threadIdx.x; e < SLAB / 4; e += 256) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < G; ++g) a += *(const f32x4*)(wsd + (((long)head * G + g) * NTILES + qt) * SLAB + e * 4);
+        *(f32x4*)(slab + e * 4) = a;
     }
     __syncthreads();
-    // this (window, head)'s partial gradients: one contiguous row of the workspace
-    float* wsrow = p.dtab_ws + ((long)win * p.nH + head) * (TT + 96);
-    for (int t = threadIdx.x; t < TT; t += NTH) wsrow[t] = tab[t] + tab[TT + t] + tab[2 * TT + t] + tab[3 * TT + t];
-    for (int t = threadIdx.x; t < 96; t += NTH) wsrow[TT + t] = padacc[t];
+    const int N = ws * ws, T1 = 2 * ws - 1;
+    for (int t = threadIdx.x; t < T1 * T1; t += 256) {
+        const int dy = t / T1 - (ws - 1), dx = t % T1 - (ws - 1);
+        float acc = 0.f;
+        for (int fr = 0; fr < 16; ++fr) {
+            const int q = qt * 16 + fr;
+            if (q >= N) break;
+            const int ky = q / ws - dy, kx = q % ws - dx;
+            if (ky < 0 || ky >= ws || kx < 0 || kx >= ws) continue;
+            const int key = ky * ws + kx;
+            acc += slab[((key >> 4) * 64 + ((key & 15) >> 2) * 16 + fr) * 4 + (key & 3)];
+        }
+        if (acc != 0.f) atomicAdd(dtab + (long)head * T1 * T1 + t, acc);
+    }
 }
 
 // expanded relative-position bias: table ((2ws-1)^2, nH) fp32 -> log2(e)-scaled bias_q [h][q][key], bias_k [h][key][q]
@@ -494,7 +590,7 @@ static int fill_params(WAttn& p, const void* qkv, const void* qkv_bias, const fl
     p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
     p.nWw = p.Wp / ws; p.nWin = (p.Hp / ws) * p.nWw; p.nWinTotal = B * p.nWin; p.N = ws * ws;
     p.scale = scale;
-    p.out = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab_ws = nullptr;
+    p.out = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab_ws = nullptr; p.dpad = nullptr;
     return UENC_OK;
 }
 
@@ -503,14 +599,35 @@ static void launch_fwd(const WAttn& p, hipStream_t stream) {
     const unsigned grid = (unsigned)((p.nWinTotal + 7) / 8 * 8 * p.nH);
     hipLaunchKernelGGL(wattn_fwd_kernel<NT>, dim3(grid), dim3(64 * NT), 0, stream, p);
 }
+// groups per head: ~one resident workgroup per CU for the 9-wave (12 x 12) case, more for small windows
+static int wattn_bwd_groups(int nWinTotal, int nH, int ntiles) {
+    const int target = ntiles >= 5 ? 256 : (ntiles >= 3 ? 512 : 1024);
+    int G = target / nH;
+    if (G < 1) G = 1;
+    if (G > nWinTotal) G = nWinTotal;
+    return G;
+}
+
 template <int NT>
-static int launch_bwd(const WAttn& p, hipStream_t stream) {
+static int launch_bwd(const WAttn& p, float* dtab, hipStream_t stream) {
     using Cf = WCfg<NT>;
     constexpr int NK2 = Cf::NK2;
+    const int G = wattn_bwd_groups(p.nWinTotal, p.nH, NT);
+    constexpr size_t shm = (size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 2 * NK2 * 4 + 96 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     const int T1 = 2 * p.ws - 1;
-    const size_t shm = (size_t)((4 * NK2 * 64 + NK2 * 4 * 3 + NK2 * 2 + NK2 + 15) / 16 * 16) + (size_t)(4 * T1 * T1 + 96) * 4;
-    const unsigned grid = (unsigned)((p.nWinTotal + 7) / 8 * 8 * p.nH);
-    hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), shm, stream, p);
+    hipError_t e = hipMemsetAsync(dtab, 0, ((size_t)p.nH * T1 * T1 + 3 * (size_t)p.C) * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    const int npair = (p.nH + 1) / 2;
+    const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
+    hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), shm, stream, p, G);
+    hipLaunchKernelGGL(wattn_dtable_kernel<NT>, dim3((unsigned)(p.nH * NT)), dim3(256), 0, stream, (const float*)p.dtab_ws, dtab, G,
+                       p.nH, p.ws);
     return UENC_OK;
 }
 
@@ -541,23 +658,29 @@ extern "C" int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const
     UENC_LAUNCH_RET();
 }
 
-// dtab_ws: (B * nWin * nH, (2ws-1)^2 + 96) fp32 scratch, fully overwritten: row (win * nH + head) holds that
-// workgroup's partial gradient of the relative-position table followed by the [3][32] (q|k|v) slice of the
-// qkv-bias gradient that reaches head `head` through padding slots (the caller sums over windows).
-extern "C" long uenc_window_attn_bwd_ws_rows(int B, int H, int W, int nH, int ws) {
-    const long Hp = (H + ws - 1) / ws, Wp = (W + ws - 1) / ws;
-    return (long)B * Hp * Wp * nH;
+// Scratch floats for the dense dS partials of uenc_window_attn_bwd.
+extern "C" long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws) {
+    if (!(B > 0 && H > 0 && W > 0 && nH > 0 && ws >= 1 && ws <= 12)) return 0;
+    const long nwin = (long)B * ((H + ws - 1) / ws) * ((W + ws - 1) / ws);
+    const int nt = wattn_ntiles(ws);
+    return (long)nH * wattn_bwd_groups((int)nwin, nH, nt) * (nt * 16) * (nt * 16);
 }
 
+// dgrads: (nH * (2ws-1)^2 + 3C) fp32, overwritten: the gradient of the relative-position table as [head][(2ws-1)^2], then
+// the q | k | v (3C) slice of the qkv-bias gradient that flows through padding slots.  dS_ws: scratch of
+// uenc_window_attn_bwd_ws_floats() floats.
 extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                                    const void* o_saved, const void* d_out, void* dqkv, float* dtab_ws,
+                                    const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dgrads,
                                     int B, int H, int W, int C, int nH, int ws, int shift, float scale, hipStream_t stream) {
     WAttn p;
     int rc = fill_params(p, qkv, qkv_bias, bias_q, bias_k, B, H, W, C, nH, ws, shift, scale);
     if (rc != UENC_OK) return rc;
-    UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dtab_ws);
-    p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab_ws = dtab_ws;
-#define CALL(NT) { rc = launch_bwd<NT>(p, stream); if (rc != UENC_OK) return rc; }
+    UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dS_ws && dgrads);
+    UENC_CHECK_ARG((((uintptr_t)o_saved | (uintptr_t)d_out | (uintptr_t)dqkv | (uintptr_t)dS_ws) & 15) == 0);
+    const int T1 = 2 * ws - 1;
+    p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab_ws = dS_ws;
+    p.dpad = dgrads + (long)nH * T1 * T1;
+#define CALL(NT) { rc = launch_bwd<NT>(p, dgrads, stream); if (rc != UENC_OK) return rc; }
     WATTN_DISPATCH(wattn_ntiles(ws), CALL)
 #undef CALL
     UENC_LAUNCH_RET();

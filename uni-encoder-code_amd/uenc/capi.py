@@ -41,8 +41,8 @@ _SIGNATURES = {
     "uenc_window_attn_np": [c_i],
     "uenc_relpos_expand": [c_p, c_p, c_p, c_i, c_i, c_p],
     "uenc_window_attn_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
-    "uenc_window_attn_bwd_ws_rows": [c_i, c_i, c_i, c_i, c_i],
-    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_window_attn_bwd_ws_floats": [c_i, c_i, c_i, c_i, c_i],
+    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 }
 
 
@@ -60,7 +60,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the ABI and the header drift apart
         fn.argtypes = argtypes
         fn.restype = c_i
-    lib.uenc_window_attn_bwd_ws_rows.restype = c_l
+    lib.uenc_window_attn_bwd_ws_floats.restype = c_l
     lib.uenc_mha_fwd_workspace_floats.restype = c_l
     lib.uenc_msdeform_attn_bwd_workspace_bytes.restype = c_l
     lib.uenc_arch.restype = ctypes.c_char_p

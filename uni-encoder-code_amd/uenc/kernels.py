@@ -145,6 +145,20 @@ def window_attn_fwd(qkv: torch.Tensor, qkv_bias16: torch.Tensor, bias_q: torch.T
     return out
 
 
+_SCRATCH = {}
+
+
+def _scratch(tag: str, nbytes: int, device) -> torch.Tensor:
+    """Kernel-internal scratch kept across calls: one buffer per (purpose, device), grown on demand.  Launches on one
+    stream are ordered, so a buffer can be reused by the next call as soon as this one is enqueued."""
+    key = (tag, str(device))
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, shift: int, scale: float):
     """Returns dqkv (B,H,W,3C) bf16, dtab (nH,(2ws-1)^2) fp32, dbias_pad (3C) fp32 (padding-slot share of qkv.bias grad)."""
     B, H, W, C3 = qkv.shape
@@ -154,15 +168,14 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
     assert o_saved.dtype == torch.bfloat16 and o_saved.is_contiguous()
     dqkv = torch.empty_like(qkv)
     TT = (2 * ws - 1) ** 2
-    rows = lib.uenc_window_attn_bwd_ws_rows(B, H, W, nH, ws)
-    # per-(window, head) partials: [table gradient (TT) | q,k,v bias gradient through padding slots (3 x 32)]
-    wsbuf = torch.empty((rows, TT + 96), dtype=torch.float32, device=qkv.device)
+    nws = int(lib.uenc_window_attn_bwd_ws_floats(B, H, W, nH, ws))
+    wsbuf = _scratch("wattn_dS", nws * 4, qkv.device)                    # dense dS partials (internal)
+    grads = torch.empty(nH * TT + 3 * C, dtype=torch.float32, device=qkv.device)
     check(lib.uenc_window_attn_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), bias_k.data_ptr(),
-                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(),
+                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(), grads.data_ptr(),
                                    B, H, W, C, nH, ws, shift, float(scale), stream_ptr()), "window_attn_bwd")
-    part = wsbuf.view(rows // nH, nH, TT + 96).sum(0)                    # (nH, TT + 96)
-    dtab = part[:, :TT]
-    dpad = part[:, TT:].reshape(nH, 3, 32).permute(1, 0, 2).reshape(3 * C)   # [q|k|v][head][32]
+    dtab = grads[:nH * TT].view(nH, TT)
+    dpad = grads[nH * TT:]                                              # [q|k|v][head][32]
     return dqkv, dtab, dpad
 
 
@@ -183,16 +196,9 @@ def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.flo
     return out
 
 
-_MSDA_WS = {}
-
-
 def _msda_workspace(nbytes: int, device) -> torch.Tensor:
-    """Scratch for the binned backward (bin counters + records), kept across calls: one buffer per device, grown on demand."""
-    buf = _MSDA_WS.get(str(device))
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _MSDA_WS[str(device)] = buf
-    return buf
+    """Scratch for the binned backward (bin counters + records)."""
+    return _scratch("msda_bins", nbytes, device)
 
 
 def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out, shapes_host=None):
