@@ -263,3 +263,51 @@ def test_param_cache_refresh(ops):
     o = ops.CACHE.mat(odd)                                              # padded entries are re-made lazily
     assert torch.equal(o[:20, :77], odd.detach().to(torch.bfloat16)) and o.shape == (24, 80)
     ops.CACHE.invalidate()
+
+
+def test_wgrad_queue_grouped_launch(ops):
+    """Deferred, grouped weight gradients == the immediate per-GEMM path (both tile classes, ragged N / K, several
+    token-range splits, accumulation into existing .grad, bias sums)."""
+    from uenc import kernels as K
+    q = ops.WGRADS
+    assert q.items[256] == 0 and q.items[128] == 0
+    g = torch.Generator().manual_seed(3)
+    probs = [(4096, 512, 256), (2048, 96, 200), (131072, 192, 64), (16384, 768, 3072), (6400, 264, 1024), (2048, 1024, 1280)]
+    want, got, keep = [], [], []
+    for (M, N, Kd) in probs:
+        dy = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        x = torch.randn(M, Kd, generator=g).to(torch.bfloat16).cuda()
+        gw0 = torch.randn(N, Kd, generator=g).cuda()
+        gb0 = torch.randn(N, generator=g).cuda()
+        gw, gb = gw0.clone(), gb0.clone()
+        K.gemm_tn(dy, x, gw, gb)                                   # immediate path
+        want.append((gw, gb))
+        gw2, gb2 = gw0.clone(), gb0.clone()
+        q.add(dy, x, gw2, gb2)                                     # outside a backward pass: flushed at once ...
+        got.append((gw2, gb2))
+        keep.append((dy, x, gw0, gb0))
+    assert q.items[256] == 0 and q.items[128] == 0
+    # ... so queue several by hand to get one multi-descriptor launch per tile class
+    multi = []
+    q.callback_armed = True
+    try:
+        for (dy, x, gw0, gb0) in keep:
+            gw3, gb3 = gw0.clone(), gb0.clone()
+            q.add(dy, x, gw3, None if dy.shape[1] == 96 else gb3)
+            multi.append((gw3, gb3))
+        assert q.items[256] > 0 and q.items[128] > 0
+    finally:
+        q.callback_armed = False
+        q.flush()
+    for (M, N, Kd), (gw, gb), (gw2, gb2), (gw3, gb3), (dy, x, gw0, gb0) in zip(probs, want, got, multi, keep):
+        ref = gw0.double() + dy.double().t() @ x.double()
+        tol = 2e-3 * float(ref.abs().max())
+        assert float((gw.double() - ref).abs().max()) < tol
+        assert float((gw2.double() - ref).abs().max()) < tol
+        assert float((gw3.double() - ref).abs().max()) < tol
+        refb = gb0.double() + dy.double().sum(0)
+        assert float((gb2.double() - refb).abs().max()) < 2e-3 * float(refb.abs().max())
+        if N != 96:
+            assert float((gb3.double() - refb).abs().max()) < 2e-3 * float(refb.abs().max())
+        else:
+            assert torch.equal(gb3, gb0)

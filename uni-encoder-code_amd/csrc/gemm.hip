@@ -666,7 +666,7 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* img, int r0, int 
 // TILE = 256: 8 waves (2 x 4), wave tile 128(k) x 64(n), 128 KB LDS, one workgroup per CU.
 // TILE = 128: 4 waves (2 x 2), wave tile  64(k) x 64(n),  64 KB LDS, two workgroups per CU (small N x K outputs, long token ranges).
 template <int TILE>
-__global__ __launch_bounds__(TILE * 2) void gemm_tnbig_kernel(GemmTN p) {
+__device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit) {
     constexpr int NTHR = TILE * 2, NWN = TILE / 64, WKT = (TILE == 256 ? 8 : 4);     // waves along n; 16-wide k tiles per wave
     constexpr int IMG = 64 * TILE * 2;                                                   // bytes of one operand image
     constexpr int RPI = NTHR * 16 / (TILE * 2);                                          // rows filled per DMA instruction
@@ -674,10 +674,9 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_kernel(GemmTN p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                 // 2 stages x (dY + X)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave / NWN, wn = wave % NWN;
-    const int tile = blockIdx.x;
     const int ntile = tile / p.tiles_k, ktile = tile - ntile * p.tiles_k;
     const int n0 = ntile * TILE, k0 = ktile * TILE;
-    const int mbeg = blockIdx.y * p.mlen;
+    const int mbeg = msplit * p.mlen;
     const int mend = min(p.M, mbeg + p.mlen);
     const int nst = (mend - mbeg) / 64;
 
@@ -779,6 +778,65 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_kernel(GemmTN p) {
             }
         }
     }
+}
+
+template <int TILE>
+__global__ __launch_bounds__(TILE * 2) void gemm_tnbig_kernel(GemmTN p) {
+    tnbig_body<TILE>(p, blockIdx.x, blockIdx.y);
+}
+
+// Grouped form: ONE launch computes many weight gradients.  The backward of a layer leaves 4 small-output wgrad GEMMs
+// (e.g. 36 tiles of 256 x 256 for a 3072 x 768 weight) that cannot fill 256 CUs unless the token range is split ~7-way,
+// each split paying a 256 KB atomic burst per tile and a pipeline fill.  Deferred and launched together (the operands
+// stay alive in HBM: there are 288 GB of it), the GEMMs of several layers give thousands of full-length work items.
+// Work item = (descriptor, output tile, token-range split); descriptors sit in device memory, item -> descriptor by
+// binary search over the exclusive prefix sum `item_begin`.
+struct TnGroupDesc {
+    const void* dY; const void* X; float* dW; float* db;
+    long ldy, ldx, ldw;
+    int M, N, K, tiles_k;
+    int mlen, nsplit, item_begin, pad_;
+};
+
+template <int TILE>
+__global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGroupDesc* __restrict__ table, int n) {
+    const int item = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].item_begin <= item) lo = mid; else hi = mid - 1;
+    }
+    const TnGroupDesc d = table[lo];
+    GemmTN p;
+    p.dY = d.dY; p.dy_f32 = 0; p.ldy = d.ldy; p.X = d.X; p.x_f32 = 0; p.ldx = d.ldx;
+    p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen;
+    const int local = item - d.item_begin;
+    tnbig_body<TILE>(p, local / d.nsplit, local % d.nsplit);
+}
+
+// table: n descriptors (device memory) of 88 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, item_begin, 0}:
+// bf16 row-major operands dY [M][N] / X [M][K] (16-byte aligned, ld % 8 == 0), M % 64 == 0, mlen % 64 == 0,
+// tiles_k = ceil(K / tile); descriptor i owns items [item_begin, item_begin + ceil(N/tile) * tiles_k * nsplit).
+// dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] (db may be NULL).  tile = 256 or 128.
+extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, hipStream_t stream) {
+    UENC_CHECK_ARG(table && n > 0 && total_items > 0 && (tile == 256 || tile == 128) && ((uintptr_t)table & 7) == 0);
+    static_assert(sizeof(TnGroupDesc) == 88, "descriptor layout is part of the ABI");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_tnbig_grouped_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256 * 2);
+        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tnbig_grouped_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2);
+        if (e1 != hipSuccess) return (int)e1;
+        if (e2 != hipSuccess) return (int)e2;
+        attr_set = true;
+    }
+    if (tile == 256)
+        hipLaunchKernelGGL(gemm_tnbig_grouped_kernel<256>, dim3((unsigned)total_items), dim3(512), 4 * 64 * 256 * 2, stream,
+                           (const TnGroupDesc*)table, n);
+    else
+        hipLaunchKernelGGL(gemm_tnbig_grouped_kernel<128>, dim3((unsigned)total_items), dim3(256), 4 * 64 * 128 * 2, stream,
+                           (const TnGroupDesc*)table, n);
+    UENC_LAUNCH_RET();
 }
 
 template <int TILE>

@@ -152,6 +152,115 @@ def _bias_pad(b: Optional[torch.Tensor], Np: int) -> Optional[torch.Tensor]:
     return torch.nn.functional.pad(b.detach(), (0, Np - b.numel()))
 
 
+class WgradQueue:
+    """Deferred weight-gradient GEMMs, launched as groups.
+
+    A layer's backward leaves a few wgrad GEMMs whose outputs are small (36 tiles of 256 x 256 for a 3072 x 768 weight):
+    alone, each must split its token range ~7-way to occupy 256 CUs and pays an atomic burst and a pipeline fill per split.
+    Nothing downstream in the backward needs dW, so the GEMMs are queued (their bf16 operands stay alive in HBM) and
+    launched together -- one `uenc_gemm_tn_grouped` per tile class -- once enough work items for a few full waves of
+    workgroups have gathered, and at the end of the backward pass (an autograd engine callback).  The gradient-ready
+    notifications of the data-parallel bucket scheduler are held back until the group that contains them is launched.
+    """
+    _DESC = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
+             ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("tiles_k", "<i4"), ("mlen", "<i4"), ("nsplit", "<i4"),
+             ("item_begin", "<i4"), ("pad", "<i4")]
+    FLUSH_ITEMS = {256: 768, 128: 1536}          # ~3 waves of workgroups (1 resp. 2 per CU)
+    TOKENS_PER_ITEM = {256: 16384, 128: 65536}   # token range of one work item (256 / 1024 k-steps of 64)
+
+    def __init__(self):
+        self.pending = {256: [], 128: []}        # tile -> [(desc tuple without item_begin, items, keepalive)]
+        self.items = {256: 0, 128: 0}
+        self.notify = []
+        self.callback_armed = False
+        self.enabled = True
+
+    @staticmethod
+    def eligible(dy, x, gw) -> bool:
+        M = dy.shape[0]
+        return (dy.dtype == BF16 and x.dtype == BF16 and dy.is_cuda and M % 64 == 0 and M >= 2048 and x.shape[0] == M
+                and dy.stride(1) == 1 and x.stride(1) == 1 and gw.stride(1) == 1
+                and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+                and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and gw.dtype == F32)
+
+    def add(self, dy, x, gw, gb, notify=()):
+        M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
+        tile = 256 if (N % 256 == 0 and Kd % 256 == 0) or (N >= 1024 and Kd >= 1024) else 128
+        nsplit = max(1, -(-M // self.TOKENS_PER_ITEM[tile]))
+        mlen = -(-(M // 64) // nsplit) * 64
+        nsplit = -(-M // mlen)
+        tiles_k = -(-Kd // tile)
+        items = -(-N // tile) * tiles_k * nsplit
+        self.pending[tile].append(((dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else 0,
+                                    dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, tiles_k, mlen, nsplit), items, (dy, x, gw, gb)))
+        self.items[tile] += items
+        self.notify.extend(p for p in notify if p is not None)
+        if not self.callback_armed:
+            try:                                  # only valid while the autograd engine is running a backward pass
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self.callback_armed = True
+            except RuntimeError:
+                pass
+        if not self.callback_armed or self.items[tile] >= self.FLUSH_ITEMS[tile]:
+            self.flush()
+
+    def _end_of_backward(self):
+        self.callback_armed = False
+        self.flush()
+
+    def flush(self):
+        """Launch everything queued (both tile classes), then release the held gradient-ready notifications."""
+        import numpy as np
+        from .capi import check, lib, stream_ptr
+        for tile in (256, 128):
+            ent = self.pending[tile]
+            if not ent:
+                continue
+            ent.sort(key=lambda e: -e[0][11])                       # longest token ranges first
+            desc = np.zeros(len(ent), dtype=self._DESC)
+            begin = 0
+            for i, (d, items, _) in enumerate(ent):
+                desc[i] = d + (begin, 0)
+                begin += items
+            dev = ent[0][2][0].device
+            host = torch.from_numpy(desc.view(np.uint8)).pin_memory()
+            tab = host.to(dev, non_blocking=True)
+            check(lib.uenc_gemm_tn_grouped(tab.data_ptr(), len(ent), begin, tile, stream_ptr()), "gemm_tn_grouped")
+            self.pending[tile] = []
+            self.items[tile] = 0
+        if self.notify:
+            params, self.notify = self.notify, []
+            _notify(*params)
+
+
+WGRADS = WgradQueue()
+
+
+def flush_wgrads():
+    """Launch any weight-gradient GEMMs still queued (called automatically at the end of every backward pass)."""
+    WGRADS.flush()
+
+
+def _tn_notify(*params):
+    """Gradient-ready notification that keeps its place behind queued wgrad groups."""
+    if WGRADS.notify or WGRADS.items[256] or WGRADS.items[128]:
+        WGRADS.notify.extend(p for p in params if p is not None)
+    else:
+        _notify(*params)
+
+
+def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor], notify=()):
+    """gw += dy^T x, gb += column sums of dy: deferred to a grouped launch when the operands allow it."""
+    if WGRADS.enabled and WGRADS.eligible(dy, x, gw):
+        WGRADS.add(dy, x, gw, gb, notify)
+        return
+    K.gemm_tn(dy, x, gw, gb)
+    if WGRADS.notify or WGRADS.items[256] or WGRADS.items[128]:
+        WGRADS.notify.extend(p for p in notify if p is not None)     # keep notification order behind the queued groups
+    else:
+        _notify(*notify)
+
+
 _BIG_M = 8192      # from this many rows on, an fp32 operand is first copied to bf16: the LDS-DMA GEMM kernels read bf16 only
 
 
@@ -176,8 +285,7 @@ def _wgrad(dy2: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, b: Optional[tor
         if rows is not None:
             gb = gb[rows[0]:rows[1]]
     if N % 8 == 0 and Kd % 8 == 0 and gw.shape == (N, Kd):
-        K.gemm_tn(dy2, x2, gw, gb)
-        _notify(w, b)
+        _tn(dy2, x2, gw, gb, (w, b))
         return
     # odd-sized tiny layers (class_embed N=20, task_mlp K=77): zero-padded scratch, then add the slice
     Np, Kp = -(-N // 8) * 8, -(-Kd // 8) * 8
@@ -390,29 +498,29 @@ class SwinBlockFn(torch.autograd.Function):
         d2h = K.cast_bf16(d2)
         dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)             # (M, 4C) d(pre-GELU)
         if train:
-            K.gemm_tn(d2h, h, grad_buf(w2), grad_buf(bb2))
+            _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
         dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))                                              # (M, C)
         if train:
-            K.gemm_tn(dh, xn2, grad_buf(w1), grad_buf(bb1))
+            _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None)
         # attention branch
         dx1h = K.cast_bf16(dx1)
         dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))                                        # (M, C) bf16
         if train:
-            K.gemm_tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj))
+            _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
         dqkv, dtab, dpad = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn,
                                              dattn.view(B, H, W, C), ws, shift, scale)
         dqkv2 = dqkv.view(M, 3 * C)
         dxn = K.gemm_nt(dqkv2, CACHE.mat_t(wqkv))
         if train:
-            K.gemm_tn(dqkv2, xn, grad_buf(wqkv), grad_buf(bqkv))
             grad_buf(bqkv).add_(dpad)
             grad_buf(table).add_(dtab.t())
+            _tn(dqkv2, xn, grad_buf(wqkv), grad_buf(bqkv), (wqkv, bqkv))
         dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
                              dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None)
         if train:
-            _notify(g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
+            _tn_notify(g1, b1, table, g2, b2)
         return (dx.view(B, L, C),) + (None,) * 19
 
 
