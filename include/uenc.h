@@ -79,9 +79,10 @@ int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dt
 
 /* Grouped weight gradients: one launch for many (dY, X, dW, db) problems of the form above (bf16 operands only).
  * table: n descriptors in DEVICE memory, 88 bytes each:
- *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, tiles_k, mlen, nsplit, item_begin, 0; }
+ *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, tiles_k, mlen, nsplit, item_begin, store; }
  * M % 64 == 0; mlen (tokens per split, % 64 == 0) * nsplit >= M; tiles_k = ceil(K / tile); item_begin = exclusive prefix
- * sum of ceil(N / tile) * tiles_k * nsplit; total_items = the full sum.  tile = 256 or 128.  Accumulates into dW / db. */
+ * sum of ceil(N / tile) * tiles_k * nsplit; total_items = the full sum.  tile = 256 or 128.  Accumulates into dW / db
+ * (atomic adds), or, for a descriptor with store != 0 and nsplit == 1, overwrites them with plain stores. */
 int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, void* stream);
 
 /* ---- LayerNorm over the last dimension (C % 4 == 0, C <= 6144) --------------------------------------

@@ -104,17 +104,26 @@ def test_layernorm_fn(ops):
 
 
 def test_mask_einsum_fn(ops):
+    """Three prediction heads on one mask-feature map: outputs, dme per head, and the hub's summed dmf (one stored GEMM)."""
     B, Q, C, HW = 2, 150, 256, 16 * 24
-    me = _r(B, Q, C, seed=1).to(torch.bfloat16).requires_grad_()
     mf = _r(B, HW, C, seed=2).requires_grad_()
     mf16 = mf.detach().to(torch.bfloat16)
-    out = ops.mask_einsum(me, mf, mf16, mf16.transpose(1, 2).contiguous())
-    dout = _r(B, Q, HW, seed=3)
-    out.backward(dout)
-    me2, mf2 = me.detach().float().requires_grad_(), mf16.float().requires_grad_()
-    out2 = torch.einsum("bqc,bkc->bqk", me2, mf2)
-    out2.backward(dout)
-    _check("out", out, out2, 1e-2); _check("dme", me.grad, me2.grad, 1e-2); _check("dmf", mf.grad, mf2.grad, 1e-2)
+    hub, group = ops.mask_feature_hub(mf)
+    mes = [_r(B, Q, C, seed=10 + i).to(torch.bfloat16).requires_grad_() for i in range(3)]
+    douts = [_r(B, Q, HW, seed=20 + i) for i in range(3)]
+    outs = [ops.mask_einsum(me, hub, mf16, mf16.transpose(1, 2).contiguous(), group) for me in mes]
+    loss = sum((o * d).sum() for o, d in zip(outs[:2], douts[:2]))          # the third head gets no gradient at all
+    loss.backward()
+    mf2 = mf16.float().requires_grad_()
+    mes2 = [me.detach().float().requires_grad_() for me in mes]
+    outs2 = [torch.einsum("bqc,bkc->bqk", me2, mf2) for me2 in mes2]
+    sum((o * d).sum() for o, d in zip(outs2[:2], douts[:2])).backward()
+    for i in range(3):
+        _check("out", outs[i], outs2[i], 1e-2)
+    for i in range(2):
+        _check("dme", mes[i].grad, mes2[i].grad, 1e-2)
+    assert mes[2].grad is None
+    _check("dmf", mf.grad, mf2.grad, 1e-2)
 
 
 @pytest.mark.parametrize("ws,H,W,nH,shift", [(7, 24, 40, 3, 3), (12, 20, 30, 2, 6)])

@@ -497,6 +497,7 @@ struct GemmTN {
     int M, N, K;
     int tiles_n, tiles_k;
     int mlen;  // tokens per split (multiple of BK)
+    int store; // tnbig only: 1 = the tile is stored (dW = ..., db = ...: single split, no prior zeroing), 0 = added atomically
 };
 
 __device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
@@ -625,7 +626,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int k = k0 + lane + 64 * q;
-                if (k < p.K) atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                if (k < p.K) {
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                }
             }
         }
     }
@@ -753,7 +757,7 @@ __device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit
             float v = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
-            if (n0 + t < p.N) atomicAdd(p.db + n0 + t, v);
+            if (n0 + t < p.N) { if (p.store) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
         }
     }
     // acc[i][j][r] = dW[n = n0 + wn*64 + j*16 + fr][k = k0 + wk*WKT*16 + i*16 + 4*fg + r]; passes of 64 n-rows
@@ -774,7 +778,10 @@ __device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit
 #pragma unroll
             for (int q = 0; q < TILE / 64; ++q) {
                 const int k = k0 + lane + 64 * q;
-                if (k < p.K) atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                if (k < p.K) {
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                }
             }
         }
     }
@@ -795,7 +802,7 @@ struct TnGroupDesc {
     const void* dY; const void* X; float* dW; float* db;
     long ldy, ldx, ldw;
     int M, N, K, tiles_k;
-    int mlen, nsplit, item_begin, pad_;
+    int mlen, nsplit, item_begin, store;
 };
 
 template <int TILE>
@@ -810,15 +817,16 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
     GemmTN p;
     p.dY = d.dY; p.dy_f32 = 0; p.ldy = d.ldy; p.X = d.X; p.x_f32 = 0; p.ldx = d.ldx;
     p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.store && d.nsplit == 1;
     const int local = item - d.item_begin;
     tnbig_body<TILE>(p, local / d.nsplit, local % d.nsplit);
 }
 
-// table: n descriptors (device memory) of 88 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, item_begin, 0}:
+// table: n descriptors (device memory) of 88 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, item_begin, store}:
 // bf16 row-major operands dY [M][N] / X [M][K] (16-byte aligned, ld % 8 == 0), M % 64 == 0, mlen % 64 == 0,
 // tiles_k = ceil(K / tile); descriptor i owns items [item_begin, item_begin + ceil(N/tile) * tiles_k * nsplit).
-// dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] (db may be NULL).  tile = 256 or 128.
+// dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] (db may be NULL); store != 0 (needs nsplit == 1): "=" instead
+// of "+=" with plain stores.  tile = 256 or 128.
 extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, hipStream_t stream) {
     UENC_CHECK_ARG(table && n > 0 && total_items > 0 && (tile == 256 || tile == 128) && ((uintptr_t)table & 7) == 0);
     static_assert(sizeof(TnGroupDesc) == 88, "descriptor layout is part of the ABI");
@@ -872,7 +880,7 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     UENC_CHECK_ARG(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0);
     GemmTN p;
     p.dY = dY; p.dy_f32 = (dy_dtype == UENC_F32); p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
-    p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
+    p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K; p.store = 0;
     // LDS-DMA paths: bf16 operands, whole 64-token stages.  256x256 tiles when the output has >= 20 of them (every split
     // of the token range costs a 256 KB atomic burst per tile, so splits are capped at 8); else 128x128 tiles, whose
     // outputs are small enough to split the token range much further.

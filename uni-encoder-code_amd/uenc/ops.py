@@ -164,7 +164,7 @@ class WgradQueue:
     """
     _DESC = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
              ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("tiles_k", "<i4"), ("mlen", "<i4"), ("nsplit", "<i4"),
-             ("item_begin", "<i4"), ("pad", "<i4")]
+             ("item_begin", "<i4"), ("store", "<i4")]
     FLUSH_ITEMS = {256: 768, 128: 1536}          # ~3 waves of workgroups (1 resp. 2 per CU)
     TOKENS_PER_ITEM = {256: 16384, 128: 65536}   # token range of one work item (256 / 1024 k-steps of 64)
 
@@ -204,28 +204,32 @@ class WgradQueue:
         if not self.callback_armed or self.items[tile] >= self.FLUSH_ITEMS[tile]:
             self.flush()
 
+    @classmethod
+    def launch(cls, tile: int, descs, device):
+        """descs: [(dy_ptr, x_ptr, dw_ptr, db_ptr, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, items, store)]."""
+        import numpy as np
+        from .capi import check, lib, stream_ptr
+        desc = np.zeros(len(descs), dtype=cls._DESC)
+        begin = 0
+        for i, d in enumerate(descs):
+            desc[i] = d[:13] + (begin, d[14])
+            begin += d[13]
+        host = torch.from_numpy(desc.view(np.uint8)).pin_memory()
+        tab = host.to(device, non_blocking=True)
+        check(lib.uenc_gemm_tn_grouped(tab.data_ptr(), len(descs), begin, tile, stream_ptr()), "gemm_tn_grouped")
+
     def _end_of_backward(self):
         self.callback_armed = False
         self.flush()
 
     def flush(self):
         """Launch everything queued (both tile classes), then release the held gradient-ready notifications."""
-        import numpy as np
-        from .capi import check, lib, stream_ptr
         for tile in (256, 128):
             ent = self.pending[tile]
             if not ent:
                 continue
             ent.sort(key=lambda e: -e[0][11])                       # longest token ranges first
-            desc = np.zeros(len(ent), dtype=self._DESC)
-            begin = 0
-            for i, (d, items, _) in enumerate(ent):
-                desc[i] = d + (begin, 0)
-                begin += items
-            dev = ent[0][2][0].device
-            host = torch.from_numpy(desc.view(np.uint8)).pin_memory()
-            tab = host.to(dev, non_blocking=True)
-            check(lib.uenc_gemm_tn_grouped(tab.data_ptr(), len(ent), begin, tile, stream_ptr()), "gemm_tn_grouped")
+            self.launch(tile, [d + (items, 0) for d, items, _ in ent], ent[0][2][0].device)
             self.pending[tile] = []
             self.items[tile] = 0
         if self.notify:
@@ -575,21 +579,85 @@ class MSDeformAttnFunction(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # mask einsum  "bqc,bchw->bqhw"  as batched NT GEMMs against channels-last mask features
 # --------------------------------------------------------------------------------------------
+class MaskFeatGrads:
+    """Collects, over the prediction heads of one decoder forward, what the gradient of the mask features needs.
+
+    Every head contributes dmf[b] += dout_h[b]^T me_h[b] (HW x C from Q = 150 rows): done per head, that is 2 x heads
+    launches that each push the whole 134 MB fp32 map through float atomics (or a read-modify-write) plus the autograd
+    engine's own accumulation.  Instead the heads only park their operands (bf16 rows of one stacked [heads*Q][HW] matrix per
+    image) and `MaskFeatHub.backward`, which autograd runs after all of them, computes the sum as ONE token-contraction
+    GEMM per image, stored once."""
+
+    def __init__(self, n_heads_hint: int = 10):
+        self.n_fwd = 0
+        self.rows = 0
+        self.dout = None        # (B, Mp, HW) bf16
+        self.me = None          # (B, Mp, C) bf16
+        self.first = True
+
+    def park(self, dout, me):
+        B, Q, HW = dout.shape
+        C = me.shape[-1]
+        if self.dout is None:
+            Mp = -(-(self.n_fwd * Q) // 64) * 64
+            self.dout = torch.empty((B, Mp, HW), dtype=BF16, device=dout.device)
+            self.me = torch.zeros((B, Mp, C), dtype=BF16, device=dout.device)       # rows never parked stay zero ...
+        r = self.rows
+        for b in range(B):
+            K.cast_bf16(dout[b], out=self.dout[b, r:r + Q])
+        self.me[:, r:r + Q] = me
+        self.rows = r + Q
+        return self.dout[:, r:r + Q]
+
+    def finish(self):
+        if self.dout is None:
+            return None
+        B, Mp, HW = self.dout.shape
+        C = self.me.shape[-1]
+        if self.rows < Mp:
+            self.dout[:, self.rows:].zero_()                                        # ... and so do theirs (0 x garbage could be NaN)
+        dmf = torch.empty((B, HW, C), dtype=F32, device=self.dout.device)
+        tile = 256 if C % 256 == 0 else 128
+        tiles_k = -(-C // tile)
+        items = -(-HW // tile) * tiles_k
+        descs = [(self.dout[b].data_ptr(), self.me[b].data_ptr(), dmf[b].data_ptr(), 0, HW, C, C, Mp, HW, C, tiles_k, Mp, 1, items, 1)
+                 for b in range(B)]
+        WgradQueue.launch(tile, descs, dmf.device)
+        self.dout = self.me = None
+        return dmf
+
+
+class MaskFeatHub(torch.autograd.Function):
+    """Identity on the mask features in front of the prediction heads; its backward produces their summed gradient."""
+
+    @staticmethod
+    def forward(ctx, mf32_tok, group):
+        ctx.group = group
+        return mf32_tok.view_as(mf32_tok)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.group.finish(), None
+
+
 class MaskEinsumFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, me, mf32_tok, mf16_tok, mf16_chw):
+    def forward(ctx, me, mf32_tok, mf16_tok, mf16_chw, group):
         """me (B, Q, C) bf16 x mask features -> (B, Q, HW) fp32.
 
-        mf32_tok (B, HW, C) fp32 is the differentiable input (its gradient is accumulated in fp32 over the
-        ten prediction heads); mf16_tok (B, HW, C) / mf16_chw (B, C, HW) are its detached bf16 operand copies.
+        mf32_tok (B, HW, C) fp32 is the differentiable input (the output of `MaskFeatHub`, which owns its gradient: see
+        `MaskFeatGrads`); mf16_tok (B, HW, C) / mf16_chw (B, C, HW) are its detached bf16 operand copies.
         """
         B, Q, C = me.shape
         HW = mf16_tok.shape[1]
+        assert HW % 8 == 0 and C % 8 == 0
         out = torch.empty((B, Q, HW), dtype=F32, device=me.device)
         for b in range(B):
             K.gemm_nt(me[b], mf16_tok[b], out=out[b])
         ctx.save_for_backward(me, mf16_chw)
         ctx.HW = HW
+        ctx.group = group
+        group.n_fwd += 1
         return out
 
     @staticmethod
@@ -597,17 +665,27 @@ class MaskEinsumFn(torch.autograd.Function):
         me, mf16_chw = ctx.saved_tensors
         B, Q, C = me.shape
         HW = ctx.HW
-        dout = dout.contiguous()
+        group = ctx.group
+        d16 = group.park(dout.contiguous(), me)
         dme = torch.zeros((B, Q, C), dtype=F32, device=me.device)
-        dmf = torch.zeros((B, HW, C), dtype=F32, device=me.device)
         for b in range(B):
-            K.gemm_nt(dout[b], mf16_chw[b], out=dme[b], splitk=max(1, min(64, HW // 2048)))
-            K.gemm_tn(dout[b], me[b], dmf[b], None, splitm=1)
-        return dme.to(me.dtype), dmf, None, None
+            K.gemm_nt(d16[b], mf16_chw[b], out=dme[b], splitk=max(1, min(64, HW // 2048)))
+        # the hub computes the real gradient; autograd only needs ONE defined (storage-free) placeholder to reach it
+        ph = None
+        if group.first:
+            group.first = False
+            ph = torch.zeros((1, 1, 1), dtype=F32, device=me.device).expand(B, HW, C)
+        return dme.to(me.dtype), ph, None, None, None
 
 
-def mask_einsum(me, mf32_tok, mf16_tok, mf16_chw):
-    return MaskEinsumFn.apply(me, mf32_tok, mf16_tok, mf16_chw)
+def mask_feature_hub(mf32_tok):
+    """-> (mf32 alias to feed `mask_einsum`, group).  One per decoder forward."""
+    group = MaskFeatGrads()
+    return MaskFeatHub.apply(mf32_tok, group), group
+
+
+def mask_einsum(me, mf32_tok, mf16_tok, mf16_chw, group):
+    return MaskEinsumFn.apply(me, mf32_tok, mf16_tok, mf16_chw, group)
 
 
 # --------------------------------------------------------------------------------------------
