@@ -58,6 +58,27 @@ int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi,
  * logits fp32 [rows][Hi][Wi]; mask u8 [rows][Ho][Wo]. */
 int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, void* stream);
 
+/* ---- FPN branch of the pixel decoder on token matrices (pixel_decoder/msdeformattn.py:283-304, :343-352) -----------
+ * y = GroupNorm(x) [+ bilinear_resize(add_src, align_corners=False)] [ReLU] for x, y (B, HW, C) fp32|bf16 (torch.nn.GroupNorm
+ * semantics over (HW x C/G) per image and group).  stats (B, G, 2) = (mean, rstd) is written for the backward; scratch:
+ * uenc_groupnorm_tokens_scratch_bytes().  add_src: NULL or fp32 (B, Hs, Ws, C), then HW == H * W.  C % G == 0, (C/G) % 4 == 0,
+ * 256 % (C/4) == 0. */
+long uenc_groupnorm_tokens_scratch_bytes(int B, int HW, int C, int G);
+int uenc_groupnorm_tokens_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                              float* stats, void* scratch, const float* add_src, int Hs, int Ws, int H, int W, int B, int HW,
+                              int C, int G, float eps, int relu, void* stream);
+/* dx (B, HW, C) fp32|bf16; dgamma / dbeta (C) accumulated (may be NULL); relu != 0: the mask is recomputed from x. */
+int uenc_groupnorm_tokens_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
+                              const float* stats, void* dx, int dx_dtype, float* dgamma, float* dbeta, void* scratch, int B,
+                              int HW, int C, int G, int relu, void* stream);
+/* adjoint of the bilinear merge: dsrc (B, Hs, Ws, C) fp32 overwritten from dy (B, H, W, C) fp32|bf16, H >= Hs, W >= Ws. */
+int uenc_upsample_bilinear_tokens_bwd(const void* dy, int dy_dtype, float* dsrc, int B, int H, int W, int Hs, int Ws, int C,
+                                      void* stream);
+/* 3x3 / stride 1 / pad 1 convolution as a GEMM (bf16, C % 8 == 0): col (B*H*W, 9*C) with column (ky, kx, c) from
+ * in (B, H, W, C), and the adjoint dx (B, H, W, C) from dcol (B*H*W, 9*C). */
+int uenc_im2col3x3(const void* in, void* col, int B, int H, int W, int C, void* stream);
+int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, void* stream);
+
 /* ---- Linear layers ---------------------------------------------------------------------------------
  * C[m][n] = epi(alpha * (sum_k A[m][k] W[n][k] + bias[n])).  A fp32|bf16 [M][K] (lda), W bf16 [N][K] (ldw),
  * C fp32|bf16 [M][N] (ldc).  K % 8 == 0, N % 4 == 0, 16-byte aligned bases.  splitk > 1 or accumulate != 0
@@ -82,8 +103,9 @@ int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dt
  *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, tiles_k, mlen, nsplit, item_begin, store; }
  * M % 64 == 0; mlen (tokens per split, % 64 == 0) * nsplit >= M; tiles_k = ceil(K / tile); item_begin = exclusive prefix
  * sum of ceil(N / tile) * tiles_k * nsplit; total_items = the full sum.  tile = 256 or 128.  Accumulates into dW / db
- * (atomic adds), or, for a descriptor with store != 0 and nsplit == 1, overwrites them with plain stores. */
-int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, void* stream);
+ * (atomic adds), or, for a descriptor with store != 0 and nsplit == 1, overwrites them with plain stores.
+ * flops = 2 * sum(M N K), used by uenc_prof_* only. */
+int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, void* stream);
 
 /* ---- LayerNorm over the last dimension (C % 4 == 0, C <= 6144) --------------------------------------
  * y = LN(x + res) * gamma + beta; optional h_out <- x + res (fp32); optional stats <- (mean, rstd) per row.

@@ -246,11 +246,11 @@ def test_conv3x3_fn(ops):
     B, H, W, Ci, Co = 2, 20, 28, 64, 128
     x = _r(B, H, W, Ci, seed=1).requires_grad_()
     w = _p(Co, Ci, 3, 3, seed=2, scale=(9 * Ci) ** -0.5)
-    y = ops.conv3x3(x, w)
-    dy = _r(B, H, W, Co, seed=3)
+    y = ops.conv3x3(x, w)                                  # fp32 channels-last input -> (B, H*W, Co)
+    dy = _r(B, H * W, Co, seed=3)
     y.backward(dy)
     x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
-    y2 = F.conv2d(x2.permute(0, 3, 1, 2), w2, padding=1).permute(0, 2, 3, 1)
+    y2 = F.conv2d(x2.permute(0, 3, 1, 2), w2, padding=1).flatten(2).transpose(1, 2)
     y2.backward(dy)
     _check("y", y, y2, 1e-2); _check("dx", x.grad, x2.grad, 1.5e-2); _check("dw", w.grad, w2.grad, 1.5e-2)
 
@@ -320,3 +320,52 @@ def test_wgrad_queue_grouped_launch(ops):
             assert float((gb3.double() - refb).abs().max()) < 2e-3 * float(refb.abs().max())
         else:
             assert torch.equal(gb3, gb0)
+
+
+@pytest.mark.parametrize("relu,merge", [(False, False), (True, False), (False, True)])
+def test_group_norm_tokens_fn(ops, relu, merge):
+    """Channels-last GroupNorm (+ ReLU / + bilinear top-down merge) against torch's NCHW ops, forward and backward."""
+    import torch.nn as nn
+    B, H, W, C, G = 2, 24, 40, 256, 32
+    gn = nn.GroupNorm(G, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(_r(C, seed=1) * 0.3 + 1.0); gn.bias.copy_(_r(C, seed=2) * 0.3)
+    x = (_r(B, H * W, C, seed=3) * 2.0 + 0.7).requires_grad_()
+    src = _r(B, H // 2, W // 2, C, seed=4).requires_grad_() if merge else None
+    y = ops.group_norm_tokens(x, gn, relu=relu, add_src=src, add_hw=(H, W) if merge else None, out_dtype=torch.float32,
+                              dx_dtype=torch.float32)
+    dy = _r(B, H * W, C, seed=5)
+    y.backward(dy)
+    got = [y.detach(), x.grad, gn.weight.grad.clone(), gn.bias.grad.clone()] + ([src.grad] if merge else [])
+    gn.zero_grad()
+    x2 = x.detach().clone().requires_grad_()
+    ref = F.group_norm(x2.transpose(1, 2).reshape(B, C, H, W), G, gn.weight, gn.bias, gn.eps)
+    if merge:
+        s2 = src.detach().clone().requires_grad_()
+        ref = ref + F.interpolate(s2.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False)
+    if relu:
+        ref = F.relu(ref)
+    ref = ref.flatten(2).transpose(1, 2)
+    ref.backward(dy)
+    want = [ref.detach(), x2.grad, gn.weight.grad, gn.bias.grad] + ([s2.grad] if merge else [])
+    for name, a, b in zip(["y", "dx", "dgamma", "dbeta", "dsrc"], got, want):
+        _check(name, a, b, 2e-5)
+    # bf16 output / bf16 incoming gradient variant (what the FPN branch uses)
+    y16 = ops.group_norm_tokens(x.detach(), gn, relu=relu, add_src=None if src is None else src.detach(), add_hw=(H, W) if merge else None,
+                                out_dtype=torch.bfloat16)
+    _check("y16", y16, ref.detach(), 1e-2)
+
+
+def test_conv3x3_tokens_fn(ops):
+    B, H, W, Ci, Co = 2, 12, 20, 64, 256
+    x = _r(B, H, W, Ci, seed=1).to(torch.bfloat16).requires_grad_()
+    w = (_r(Co, Ci, 3, 3, seed=2) * (9 * Ci) ** -0.5).requires_grad_()
+    y = ops.conv3x3(x, w)
+    dy = _r(B, H * W, Co, seed=3)
+    y.backward(dy)
+    x2 = x.detach().float().requires_grad_()
+    w2 = w.detach().to(torch.bfloat16).float().requires_grad_()
+    ref = F.conv2d(x2.permute(0, 3, 1, 2), w2, padding=1).flatten(2).transpose(1, 2)
+    ref.backward(dy.to(torch.bfloat16).float())
+    _check("y", y, ref, 1e-2); _check("dx", x.grad, x2.grad, 2e-2); _check("dw", w.grad, w2.grad, 2e-2)
+    ops.CACHE.invalidate()

@@ -827,7 +827,7 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
 // tiles_k = ceil(K / tile); descriptor i owns items [item_begin, item_begin + ceil(N/tile) * tiles_k * nsplit).
 // dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] (db may be NULL); store != 0 (needs nsplit == 1): "=" instead
 // of "+=" with plain stores.  tile = 256 or 128.
-extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, hipStream_t stream) {
+extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, hipStream_t stream) {
     UENC_CHECK_ARG(table && n > 0 && total_items > 0 && (tile == 256 || tile == 128) && ((uintptr_t)table & 7) == 0);
     static_assert(sizeof(TnGroupDesc) == 88, "descriptor layout is part of the ABI");
     static bool attr_set = false;
@@ -838,12 +838,15 @@ extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, i
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
+    const bool prof = uenc_prof_on();
+    if (prof) uenc_prof_begin(UENC_PROF_GEMM_TN, flops, stream);          // flops: 2 * sum(M N K), for the profiler only
     if (tile == 256)
         hipLaunchKernelGGL(gemm_tnbig_grouped_kernel<256>, dim3((unsigned)total_items), dim3(512), 4 * 64 * 256 * 2, stream,
                            (const TnGroupDesc*)table, n);
     else
         hipLaunchKernelGGL(gemm_tnbig_grouped_kernel<128>, dim3((unsigned)total_items), dim3(256), 4 * 64 * 128 * 2, stream,
                            (const TnGroupDesc*)table, n);
+    if (prof) uenc_prof_end(stream);
     UENC_LAUNCH_RET();
 }
 

@@ -28,8 +28,14 @@ _SIGNATURES = {
     "uenc_upsample_bilinear": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_attn_mask": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_nt": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_i, c_p],
+    "uenc_groupnorm_tokens_scratch_bytes": [c_i, c_i, c_i, c_i],
+    "uenc_groupnorm_tokens_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
+    "uenc_groupnorm_tokens_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_upsample_bilinear_tokens_bwd": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_im2col3x3": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "uenc_col2im3x3": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_tn": [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
-    "uenc_gemm_tn_grouped": [c_p, c_i, c_i, c_i, c_p],
+    "uenc_gemm_tn_grouped": [c_p, c_i, c_i, c_i, ctypes.c_double, c_p],
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p],
     "uenc_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p],
     "uenc_msdeform_attn_fwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -64,6 +70,7 @@ def _load():
     lib.uenc_window_attn_bwd_ws_floats.restype = c_l
     lib.uenc_mha_fwd_workspace_floats.restype = c_l
     lib.uenc_msdeform_attn_bwd_workspace_bytes.restype = c_l
+    lib.uenc_groupnorm_tokens_scratch_bytes.restype = c_l
     lib.uenc_arch.restype = ctypes.c_char_p
     lib.uenc_arch.argtypes = []
     return lib

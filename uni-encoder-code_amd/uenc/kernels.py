@@ -246,3 +246,62 @@ def upsample_bilinear(x: torch.Tensor, size) -> torch.Tensor:
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
     check(lib.uenc_upsample_bilinear(x.data_ptr(), out.data_ptr(), N * C, Hi, Wi, Ho, Wo, stream_ptr()), "upsample_bilinear")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# FPN branch on token matrices
+# --------------------------------------------------------------------------------------------
+def groupnorm_tokens_fwd(x, gamma, beta, G: int, eps: float, *, relu=False, add_src=None, add_hw=None, out_dtype=torch.float32):
+    """x (B, HW, C) fp32|bf16 -> (y (B, HW, C) out_dtype, stats (B, G, 2)).  add_src: fp32 (B, Hs, Ws, C) merged in by
+    bilinear resize to add_hw = (H, W)."""
+    B, HW, C = x.shape
+    assert x.is_cuda and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    y = torch.empty((B, HW, C), dtype=out_dtype, device=x.device)
+    stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    scratch = _scratch("gn", int(lib.uenc_groupnorm_tokens_scratch_bytes(B, HW, C, G)), x.device)
+    Hs = Ws = H = W = 0
+    if add_src is not None:
+        assert add_src.dtype == torch.float32 and add_src.is_contiguous() and add_src.shape[0] == B and add_src.shape[3] == C
+        Hs, Ws = add_src.shape[1], add_src.shape[2]
+        H, W = add_hw
+    check(lib.uenc_groupnorm_tokens_fwd(x.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), dt(y), stats.data_ptr(),
+                                        scratch.data_ptr(), ptr(add_src), Hs, Ws, H, W, B, HW, C, G, float(eps), int(relu),
+                                        stream_ptr()), "groupnorm_tokens_fwd")
+    return y, stats
+
+
+def groupnorm_tokens_bwd(dy, x, gamma, beta, stats, G: int, *, relu=False, dgamma=None, dbeta=None, dx_dtype=torch.bfloat16):
+    B, HW, C = x.shape
+    assert dy.is_contiguous() and dy.shape == x.shape and x.is_contiguous()
+    dx = torch.empty((B, HW, C), dtype=dx_dtype, device=x.device)
+    scratch = _scratch("gn", int(lib.uenc_groupnorm_tokens_scratch_bytes(B, HW, C, G)), x.device)
+    check(lib.uenc_groupnorm_tokens_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                        dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), scratch.data_ptr(), B, HW, C, G, int(relu),
+                                        stream_ptr()), "groupnorm_tokens_bwd")
+    return dx
+
+
+def upsample_bilinear_tokens_bwd(dy, Hs: int, Ws: int):
+    """dy (B, H, W, C) fp32|bf16 -> (B, Hs, Ws, C) fp32: adjoint of the align_corners=False bilinear resize (Hs, Ws) -> (H, W)."""
+    B, H, W, C = dy.shape
+    assert dy.is_contiguous()
+    out = torch.empty((B, Hs, Ws, C), dtype=torch.float32, device=dy.device)
+    check(lib.uenc_upsample_bilinear_tokens_bwd(dy.data_ptr(), dt(dy), out.data_ptr(), B, H, W, Hs, Ws, C, stream_ptr()),
+          "upsample_bilinear_tokens_bwd")
+    return out
+
+
+def im2col3x3(x16):
+    """(B, H, W, C) bf16 -> (B*H*W, 9*C) bf16 patch matrix, column order (ky, kx, c)."""
+    B, H, W, C = x16.shape
+    assert x16.dtype == torch.bfloat16 and x16.is_contiguous()
+    col = torch.empty((B * H * W, 9 * C), dtype=torch.bfloat16, device=x16.device)
+    check(lib.uenc_im2col3x3(x16.data_ptr(), col.data_ptr(), B, H, W, C, stream_ptr()), "im2col3x3")
+    return col
+
+
+def col2im3x3(dcol, B: int, H: int, W: int, C: int):
+    assert dcol.dtype == torch.bfloat16 and dcol.is_contiguous() and dcol.numel() == B * H * W * 9 * C
+    dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dcol.device)
+    check(lib.uenc_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "col2im3x3")
+    return dx

@@ -29,14 +29,23 @@ def _tokens(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 2, 3, 1).reshape(B, H * W, C)
 
 
-def _conv1x1_gn(tok: torch.Tensor, conv: nn.Module, gn: Optional[nn.Module], H: int, W: int) -> torch.Tensor:
-    """1x1 conv (GEMM) + GroupNorm on channels-last tokens -> (B, HW, D) fp32."""
+def _conv1x1_gn(tok: torch.Tensor, conv: nn.Module, gn: Optional[nn.Module], H: int, W: int, **gn_kw) -> torch.Tensor:
+    """1x1 conv (GEMM) + GroupNorm on channels-last tokens -> (B, HW, D); gn_kw: see ops.group_norm_tokens."""
     y = ops.linear(tok, conv.weight, conv.bias, out_dtype=torch.float32)
     if gn is None:
         return y
+    if isinstance(gn, nn.GroupNorm) and _gn_tokens_ok(gn):
+        return ops.group_norm_tokens(y, gn, **gn_kw)
+    assert not gn_kw
     B, HW, D = y.shape
     y = F.group_norm(y.transpose(1, 2).reshape(B, D, H, W), gn.num_groups, gn.weight, gn.bias, gn.eps)
     return y.flatten(2).transpose(1, 2)
+
+
+def _gn_tokens_ok(gn: nn.Module) -> bool:
+    """Shapes the channels-last GroupNorm kernels take (the reference's GN(32, 256) does)."""
+    C, G = gn.num_channels, gn.num_groups
+    return gn.affine and C % G == 0 and (C // G) % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
@@ -195,17 +204,31 @@ class MSDeformAttnPixelDecoder(nn.Module):
         y, spatial_shapes, level_start_index, _ = self.transformer(srcs, pos, shapes)
         bs = y.shape[0]
         out, start = [], 0
-        for (H, W) in shapes:
-            out.append(y[:, start:start + H * W].transpose(1, 2).reshape(bs, -1, H, W))
+        for (H, W) in shapes:                          # channels-last views of the encoder output, no copies
+            out.append(y[:, start:start + H * W].view(bs, H, W, -1).permute(0, 3, 1, 2))
             start += H * W
+        last_tok = None
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             x = features[f].float()
             B, _, H, W = x.shape
             lat, outc = self.lateral_convs[idx], self.output_convs[idx]
+            fused = (isinstance(lat.norm, nn.GroupNorm) and isinstance(outc.norm, nn.GroupNorm) and _gn_tokens_ok(lat.norm)
+                     and _gn_tokens_ok(outc.norm) and outc.kernel_size == (3, 3) and outc.bias is None and outc.stride == (1, 1)
+                     and outc.padding == (1, 1) and outc.activation is F.relu and outc.in_channels % 8 == 0)
+            if fused:
+                # the whole branch on token matrices: GN + top-down merge in one pass (bf16 out = the conv's patch source),
+                # conv as patch GEMM, GN + ReLU in one pass (bf16 out = the next GEMM's operand)
+                prev = out[-1].permute(0, 2, 3, 1)                                          # (B, Hs, Ws, C) view
+                yy = _conv1x1_gn(_tokens(x), lat, lat.norm, H, W, add_src=prev, add_hw=(H, W), out_dtype=torch.bfloat16)
+                z = ops.conv3x3(yy.view(B, H, W, -1), outc.weight)                          # (B, HW, C) fp32
+                last_tok = ops.group_norm_tokens(z, outc.norm, relu=True, out_dtype=torch.bfloat16)
+                out.append(last_tok.view(B, H, W, -1).permute(0, 3, 1, 2))
+                continue
+            last_tok = None
             cur = _conv1x1_gn(_tokens(x), lat, lat.norm, H, W).transpose(1, 2).reshape(B, -1, H, W)
-            yy = cur + F.interpolate(out[-1], size=(H, W), mode="bilinear", align_corners=False)
+            yy = cur + F.interpolate(out[-1].float(), size=(H, W), mode="bilinear", align_corners=False)
             if outc.kernel_size == (3, 3) and outc.bias is None and outc.stride == (1, 1) and outc.padding == (1, 1):
-                z = ops.conv3x3(yy.permute(0, 2, 3, 1), outc.weight).permute(0, 3, 1, 2)        # im2col + MFMA GEMM
+                z = ops.conv3x3(yy.permute(0, 2, 3, 1), outc.weight).view(B, H, W, -1).permute(0, 3, 1, 2)   # im2col + MFMA GEMM
                 if outc.norm is not None:
                     z = outc.norm(z)
                 out.append(outc.activation(z) if outc.activation is not None else z)
@@ -214,5 +237,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         multi_scale_features = out[:self.oneformer_num_feature_levels]
         last = out[-1]
         B, _, H, W = last.shape
-        mf = ops.linear(_tokens(last), self.mask_features.weight, self.mask_features.bias, out_dtype=torch.float32)
-        return mf.transpose(1, 2).reshape(B, -1, H, W), out[0], multi_scale_features
+        mf = ops.linear(last_tok if last_tok is not None else _tokens(last), self.mask_features.weight, self.mask_features.bias,
+                        out_dtype=torch.float32)
+        # mask features stay channels-last in memory ((B, C, H, W) view): the decoder consumes them as tokens
+        return mf.view(B, H, W, -1).permute(0, 3, 1, 2), out[0], multi_scale_features

@@ -210,13 +210,14 @@ class WgradQueue:
         import numpy as np
         from .capi import check, lib, stream_ptr
         desc = np.zeros(len(descs), dtype=cls._DESC)
-        begin = 0
+        begin, flops = 0, 0.0
         for i, d in enumerate(descs):
             desc[i] = d[:13] + (begin, d[14])
             begin += d[13]
+            flops += 2.0 * d[7] * d[8] * d[9]
         host = torch.from_numpy(desc.view(np.uint8)).pin_memory()
         tab = host.to(device, non_blocking=True)
-        check(lib.uenc_gemm_tn_grouped(tab.data_ptr(), len(descs), begin, tile, stream_ptr()), "gemm_tn_grouped")
+        check(lib.uenc_gemm_tn_grouped(tab.data_ptr(), len(descs), begin, tile, flops, stream_ptr()), "gemm_tn_grouped")
 
     def _end_of_backward(self):
         self.callback_armed = False
@@ -700,11 +701,52 @@ def attention(q, k, v, nheads: int, mask: Optional[torch.Tensor] = None) -> torc
 # --------------------------------------------------------------------------------------------
 # 3x3 convolution (stride 1, pad 1, no bias) on channels-last maps as im2col + MFMA GEMM
 # --------------------------------------------------------------------------------------------
+class GroupNormTokensFn(torch.autograd.Function):
+    """torch.nn.GroupNorm on a token matrix (B, HW, C) [+ bilinear top-down merge] [+ ReLU], channels-last throughout
+    (reference pixel_decoder/msdeformattn.py:283-302 norm layers, :343-352 merge)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, relu, add_src, add_hw, out_dtype, dx_dtype):
+        xc = x if x.is_contiguous() else x.contiguous()
+        src = None
+        if add_src is not None:
+            src = add_src.float()
+            src = src if src.is_contiguous() else src.contiguous()
+        y, stats = K.groupnorm_tokens_fwd(xc, gamma.detach(), beta.detach(), G, eps, relu=relu, add_src=src, add_hw=add_hw,
+                                          out_dtype=out_dtype)
+        ctx.save_for_backward(xc, gamma, beta, stats)
+        ctx.cfg = (G, relu, add_hw, None if add_src is None else tuple(add_src.shape), dx_dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        G, relu, add_hw, src_shape, dx_dtype = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        train = gamma.requires_grad
+        dx = K.groupnorm_tokens_bwd(dy, x, gamma.detach(), beta.detach(), stats, G, relu=relu,
+                                    dgamma=grad_buf(gamma) if train else None, dbeta=grad_buf(beta) if train else None,
+                                    dx_dtype=dx_dtype)
+        if train:
+            _tn_notify(gamma, beta)
+        dsrc = None
+        if src_shape is not None and ctx.needs_input_grad[6]:
+            B, Hs, Ws, C = src_shape
+            dsrc = K.upsample_bilinear_tokens_bwd(dy.view(B, add_hw[0], add_hw[1], C), Hs, Ws)      # (the ReLU is never combined with a merge)
+        return dx, None, None, None, None, None, dsrc, None, None, None
+
+
+def group_norm_tokens(x, gn, *, relu=False, add_src=None, add_hw=None, out_dtype=F32, dx_dtype=BF16):
+    """`gn`: an nn.GroupNorm; x (B, HW, C); add_src (B, Hs, Ws, C) fp32 is resized to add_hw = (H, W) and added."""
+    assert not (relu and add_src is not None)
+    return GroupNormTokensFn.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, add_src, add_hw, out_dtype, dx_dtype)
+
+
 class Conv3x3Fn(torch.autograd.Function):
     """The single 3x3 conv of the FPN (reference pixel_decoder/msdeformattn.py:293-302 `layer_1`, 154 GFLOP per image
-    at 1/4 resolution).  x (B, H, W, Cin) channels-last; weight (Cout, Cin, 3, 3).  Forward: one strided gather
-    into the (B*H*W, 9*Cin) bf16 patch matrix, then the 256x256 LDS-DMA GEMM; backward: dgrad GEMM + 9 shifted
-    adds (col2im), wgrad through the token-contraction GEMM on the saved patch matrix."""
+    at 1/4 resolution).  x (B, H, W, Cin) bf16 channels-last; weight (Cout, Cin, 3, 3) -> (B, H*W, Cout) fp32.  Forward:
+    patch matrix (B*H*W, 9*Cin) + the 256x256 LDS-DMA GEMM; backward: dgrad GEMM + col2im gather, wgrad through the
+    token-contraction GEMM on the saved patch matrix."""
 
     @staticmethod
     def _wmat(weight):
@@ -718,35 +760,47 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         B, H, W, C = x.shape
-        xp = torch.nn.functional.pad(x.to(BF16), (0, 0, 1, 1, 1, 1))                       # (B, H+2, W+2, C)
-        sB, sH, sW, sC = xp.stride()
-        col = xp.as_strided((B, H, W, 3, 3, C), (sB, sH, sW, sH, sW, sC)).reshape(B * H * W, 9 * C)   # one gather copy
+        x16 = x if x.dtype == BF16 else x.to(BF16)
+        col = K.im2col3x3(x16 if x16.is_contiguous() else x16.contiguous())
         out = K.gemm_nt(col, Conv3x3Fn._wmat(weight), out_dtype=F32)
         ctx.save_for_backward(col, weight)
         ctx.shape = (B, H, W, C)
-        return out.view(B, H, W, weight.shape[0])
+        ctx.in_dtype = x.dtype
+        return out.view(B, H * W, weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         col, weight = ctx.saved_tensors
         B, H, W, C = ctx.shape
         Co = weight.shape[0]
-        dy2 = K.cast_bf16(dy.reshape(B * H * W, Co).contiguous().float())
+        dy2 = dy.reshape(B * H * W, Co)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        if dy2.dtype != BF16:
+            dy2 = K.cast_bf16(dy2.float())
         dx = None
         if ctx.needs_input_grad[0]:
-            dcol = K.gemm_nt(dy2, Conv3x3Fn._wmat_t(weight)).view(B, H, W, 3, 3, C)          # (M, 9*Cin) bf16
-            dxp = torch.zeros((B, H + 2, W + 2, C), dtype=F32, device=dy.device)
-            for ky in range(3):
-                for kx in range(3):
-                    dxp[:, ky:ky + H, kx:kx + W].add_(dcol[:, :, :, ky, kx])
-            dx = dxp[:, 1:H + 1, 1:W + 1]
+            dcol = K.gemm_nt(dy2, Conv3x3Fn._wmat_t(weight))                                  # (M, 9*Cin) bf16
+            dx = K.col2im3x3(dcol, B, H, W, C)
+            if ctx.in_dtype != BF16:
+                dx = dx.to(ctx.in_dtype)
         if weight.requires_grad:
+            M = B * H * W
             dw = torch.zeros((Co, 9 * C), dtype=F32, device=dy.device)
-            K.gemm_tn(dy2, col, dw, None)
+            if M % 64 == 0 and Co % 8 == 0:
+                tile = 256 if Co % 256 == 0 else 128
+                nsplit = max(1, M // 16384)
+                mlen = -(-(M // 64) // nsplit) * 64
+                nsplit = -(-M // mlen)
+                tiles_k = -(-(9 * C) // tile)
+                WgradQueue.launch(tile, [(dy2.data_ptr(), col.data_ptr(), dw.data_ptr(), 0, Co, 9 * C, 9 * C, M, Co, 9 * C, tiles_k, mlen,
+                                          nsplit, -(-Co // tile) * tiles_k * nsplit, 0)], dy.device)
+            else:
+                K.gemm_tn(dy2, col, dw, None)
             grad_buf(weight).add_(dw.view(Co, 3, 3, C).permute(0, 3, 1, 2))
-            _notify(weight)
+            _tn_notify(weight)
         return dx, None
 
 
 def conv3x3(x_nhwc, weight):
+    """x (B, H, W, Cin) bf16|fp32 channels-last -> (B, H*W, Cout) fp32."""
     return Conv3x3Fn.apply(x_nhwc, weight)
