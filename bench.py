@@ -214,7 +214,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(achieved / 2500.0, 4), "traffic": None, "launches_per_step": n // max(args.steps, 1),
                          "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
-                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)},
+                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3),
+                         "families": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,
+                                          "ms_per_step": round(v[0] / max(args.steps, 1), 2), "launches_per_step": v[2] // max(args.steps, 1)}
+                                      for k, v in fams.items()}},
             "loss": round(float(loss), 5), "hip_graph": graph is not None,
         }
         if world == 1 and not args.no_cpu_baseline:

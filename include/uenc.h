@@ -62,7 +62,7 @@ int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi
  * y = GroupNorm(x) [+ bilinear_resize(add_src, align_corners=False)] [ReLU] for x, y (B, HW, C) fp32|bf16 (torch.nn.GroupNorm
  * semantics over (HW x C/G) per image and group).  stats (B, G, 2) = (mean, rstd) is written for the backward; scratch:
  * uenc_groupnorm_tokens_scratch_bytes().  add_src: NULL or fp32 (B, Hs, Ws, C), then HW == H * W.  C % G == 0, (C/G) % 4 == 0,
- * 256 % (C/4) == 0. */
+ * 64 % (C/G) == 0, 256 % (C/4) == 0. */
 long uenc_groupnorm_tokens_scratch_bytes(int B, int HW, int C, int G);
 int uenc_groupnorm_tokens_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                               float* stats, void* scratch, const float* add_src, int Hs, int Ws, int H, int W, int B, int HW,

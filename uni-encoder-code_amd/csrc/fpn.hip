@@ -94,48 +94,62 @@ __global__ __launch_bounds__(GN_THREADS) void gn_reduce_kernel(GnP p) {
     }
 }
 
-// pass 2 of forward: one thread per (image, group): mean and rstd from the fp64 partials
-__global__ void gn_stats_kernel(GnP p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.B * p.G) return;
-    const int b = i / p.G, g = i - b * p.G, cpg = p.C / p.G;
-    double s = 0, ss = 0;
-    for (int ch = 0; ch < p.nchunk; ++ch)
-        for (int j = 0; j < cpg; ++j) {
-            const double* e = p.part + (((long)b * p.nchunk + ch) * p.C + g * cpg + j) * 2;
-            s += e[0]; ss += e[1];
-        }
-    const double n = (double)p.HW * cpg, mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0) var = 0;
-    p.stats[(long)i * 2] = (float)mean;
-    p.stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
-// pass 2 of backward: one workgroup per image; per-channel totals -> dgamma / dbeta (+=, atomics over images) and the
-// per-group coefficients c1 = mean_g(dy gamma), c2 = mean_g(dy gamma xhat)
+// pass 2 of forward: one wave per (image, group): mean and rstd from the fp64 partials
+__global__ __launch_bounds__(64) void gn_stats_kernel(GnP p) {
+    const int i = blockIdx.x, b = i / p.G, g = i - b * p.G, cpg = p.C / p.G;
+    double s = 0, ss = 0;
+    for (int e = threadIdx.x; e < p.nchunk * cpg; e += 64) {
+        const int ch = e / cpg, j = e - ch * cpg;
+        const double* q = p.part + (((long)b * p.nchunk + ch) * p.C + g * cpg + j) * 2;
+        s += q[0]; ss += q[1];
+    }
+    s = wave_sum_f64(s); ss = wave_sum_f64(ss);
+    if (threadIdx.x == 0) {
+        const double n = (double)p.HW * cpg, mean = s / n;
+        double var = ss / n - mean * mean;
+        if (var < 0) var = 0;
+        p.stats[(long)i * 2] = (float)mean;
+        p.stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+}
+
+// pass 2 of backward: one workgroup per (image, 64 channels): per-channel totals -> dgamma / dbeta (+=, atomics over images)
+// and, for the groups inside these 64 channels, c1 = mean_g(dy gamma), c2 = mean_g(dy gamma xhat)
 __global__ __launch_bounds__(GN_THREADS) void gn_bwd_coef_kernel(GnP p) {
-    __shared__ double s1[1024], s2[1024];
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < p.C; c += GN_THREADS) {
-        double a = 0, q = 0;
-        for (int ch = 0; ch < p.nchunk; ++ch) {
+    __shared__ double sa[4][64], sq[4][64];
+    const int nblk = (p.C + 63) / 64, b = blockIdx.x / nblk, c0 = (blockIdx.x - b * nblk) * 64;
+    const int cl = threadIdx.x & 63, r = threadIdx.x >> 6, c = c0 + cl;
+    double a = 0, q = 0;
+    if (c < p.C)
+        for (int ch = r; ch < p.nchunk; ch += 4) {
             const double* e = p.part + (((long)b * p.nchunk + ch) * p.C + c) * 2;
             a += e[0]; q += e[1];
         }
+    sa[r][cl] = a; sq[r][cl] = q;
+    __syncthreads();
+    if (r == 0 && c < p.C) {
+        a = sa[0][cl] + sa[1][cl] + sa[2][cl] + sa[3][cl];
+        q = sq[0][cl] + sq[1][cl] + sq[2][cl] + sq[3][cl];
         if (p.dbeta != nullptr) atomicAdd(p.dbeta + c, (float)a);
         if (p.dgamma != nullptr) atomicAdd(p.dgamma + c, (float)q);
         const double gm = (double)p.gamma[c];
-        s1[c] = a * gm; s2[c] = q * gm;
+        sa[0][cl] = a * gm; sq[0][cl] = q * gm;
     }
     __syncthreads();
-    const int cpg = p.C / p.G;
-    for (int g = threadIdx.x; g < p.G; g += GN_THREADS) {
-        double a = 0, q = 0;
-        for (int j = 0; j < cpg; ++j) { a += s1[g * cpg + j]; q += s2[g * cpg + j]; }
+    const int cpg = p.C / p.G;                       // divides 64 (checked by the launcher)
+    if (threadIdx.x < 64 / cpg && c0 + threadIdx.x * cpg < p.C) {
+        double s1 = 0, s2 = 0;
+        for (int j = 0; j < cpg; ++j) { s1 += sa[0][threadIdx.x * cpg + j]; s2 += sq[0][threadIdx.x * cpg + j]; }
         const double n = (double)p.HW * cpg;
-        p.coef[((long)b * p.G + g) * 2] = (float)(a / n);
-        p.coef[((long)b * p.G + g) * 2 + 1] = (float)(q / n);
+        const int g = c0 / cpg + threadIdx.x;
+        p.coef[((long)b * p.G + g) * 2] = (float)(s1 / n);
+        p.coef[((long)b * p.G + g) * 2 + 1] = (float)(s2 / n);
     }
 }
 
@@ -198,23 +212,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnP p) {
 static int gn_fill(GnP& p, const void* x, int x_dtype, const float* gamma, const float* beta, float* stats, void* scratch, int B,
                    int HW, int C, int G) {
     if (!(x && gamma && beta && stats && scratch && B > 0 && HW > 0 && G > 0)) return UENC_EINVAL;
-    if (!(C % G == 0 && (C / G) % 4 == 0 && C % 4 == 0 && C <= 1024 && GN_THREADS % (C / 4) == 0)) return UENC_EINVAL;
+    if (!(C % G == 0 && (C / G) % 4 == 0 && 64 % (C / G) == 0 && C <= 1024 && GN_THREADS % (C / 4) == 0)) return UENC_EINVAL;
     if (!(x_dtype == UENC_F32 || x_dtype == UENC_BF16) || ((uintptr_t)x & 15) || ((uintptr_t)scratch & 15)) return UENC_EINVAL;
     p.x = x; p.x_f32 = (x_dtype == UENC_F32); p.gamma = gamma; p.beta = beta; p.stats = stats;
     p.part = (double*)scratch;
     p.B = B; p.HW = HW; p.C = C; p.G = G;
-    int nchunk = (HW + 1023) / 1024;
-    if (nchunk > 256) nchunk = 256;
+    int nchunk = (HW + 127) / 128;                    // >= 4 workgroups per CU at 1/4 resolution; 128+ tokens each
+    if (nchunk > 1024) nchunk = 1024;
     p.nchunk = nchunk;
     p.coef = nullptr; p.dgamma = p.dbeta = nullptr; p.add_src = nullptr; p.dy = nullptr; p.y = nullptr; p.relu = 0;
     p.H = p.W = p.Hs = p.Ws = 0; p.eps = 0.f; p.y_f32 = 0; p.dy_f32 = 0;
     return UENC_OK;
 }
 
-// scratch bytes for uenc_groupnorm_tokens_fwd / _bwd: fp64 partial sums (B, nchunk <= 256, C, 2) + (B, G, 2) floats
+// scratch bytes for uenc_groupnorm_tokens_fwd / _bwd: fp64 partial sums (B, nchunk <= 1024, C, 2) + (B, G, 2) floats
 extern "C" long uenc_groupnorm_tokens_scratch_bytes(int B, int HW, int C, int G) {
-    long nchunk = ((long)HW + 1023) / 1024;
-    if (nchunk > 256) nchunk = 256;
+    long nchunk = ((long)HW + 127) / 128;
+    if (nchunk > 1024) nchunk = 1024;
     return (long)B * nchunk * C * 2 * 8 + (long)B * G * 2 * 4 + 256;
 }
 
@@ -230,7 +244,7 @@ extern "C" int uenc_groupnorm_tokens_fwd(const void* x, int x_dtype, const float
     UENC_CHECK_ARG(add_src == nullptr || (Hs > 0 && Ws > 0 && H > 0 && W > 0 && (long)H * W == HW));
     p.y = y; p.y_f32 = (y_dtype == UENC_F32); p.eps = eps; p.relu = relu; p.add_src = add_src; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws;
     hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(p.nchunk, B), dim3(GN_THREADS), 0, stream, p);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((B * G + 63) / 64), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(64), 0, stream, p);
     const long total = (long)B * HW * (C / 4);
     long blocks = (total + GN_THREADS - 1) / GN_THREADS;
     if (blocks > 8192) blocks = 8192;
@@ -251,7 +265,7 @@ extern "C" int uenc_groupnorm_tokens_bwd(const void* dy, int dy_dtype, const voi
     p.dgamma = dgamma; p.dbeta = dbeta;
     p.coef = (float*)((char*)scratch + (long)B * p.nchunk * C * 2 * 8);
     hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(p.nchunk, B), dim3(GN_THREADS), 0, stream, p);
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B), dim3(GN_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B * ((C + 63) / 64)), dim3(GN_THREADS), 0, stream, p);
     const long total = (long)B * HW * (C / 4);
     long blocks = (total + GN_THREADS - 1) / GN_THREADS;
     if (blocks > 8192) blocks = 8192;

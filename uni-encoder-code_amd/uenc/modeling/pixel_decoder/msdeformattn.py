@@ -45,7 +45,7 @@ def _conv1x1_gn(tok: torch.Tensor, conv: nn.Module, gn: Optional[nn.Module], H: 
 def _gn_tokens_ok(gn: nn.Module) -> bool:
     """Shapes the channels-last GroupNorm kernels take (the reference's GN(32, 256) does)."""
     C, G = gn.num_channels, gn.num_groups
-    return gn.affine and C % G == 0 and (C // G) % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0
+    return gn.affine and C % G == 0 and (C // G) % 4 == 0 and 64 % (C // G) == 0 and C <= 1024 and 256 % (C // 4) == 0
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
