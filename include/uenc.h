@@ -112,10 +112,14 @@ int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, do
  * Replaces nn.LayerNorm and the preceding residual add of swin.py:247,293,334,492,673,
  * msdeformattn.py:128-129,136-137, transformer.py:268-297, oneformer_transformer_decoder.py:66-67,126-127,184-185,496. */
 int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtype, float* h_out, const float* gamma,
-                       const float* beta, void* y, int y_dtype, float* stats, long M, int C, float eps, void* stream);
-/* dx = LN'(dy) [+ dres];  dgamma / dbeta accumulated (both NULL to skip). */
+                       const float* beta, void* y, int y_dtype, float* stats, long M, int C, float eps, void* y16,
+                       void* stream);
+/* dx = LN'(dy) [+ dres];  dgamma / dbeta accumulated (both NULL to skip).
+ * y16 / dx16 (may be NULL): a bf16 copy of y / dx written in the same pass -- the operand the next GEMM reads, so that an
+ * fp32 stream needs no separate cast kernel. */
 int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats, const float* gamma,
-                       const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* stream);
+                       const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* dx16,
+                       void* stream);
 
 /* ---- shifted-window attention (head_dim 32, window <= 12) ---------------------------------------------
  * Replaces F.pad -> torch.roll -> window_partition -> WindowAttention core -> window_reverse -> roll -> crop,

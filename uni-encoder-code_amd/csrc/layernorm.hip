@@ -16,6 +16,7 @@ struct LnFwd {
     float* h_out;                     // optional: x + res (fp32), the tensor that is normalised
     const float* gamma; const float* beta;
     void* y; int y_f32;
+    bf16* y16;                        // optional bf16 twin of y (the next GEMM's operand) when y is fp32
     float2* stats;                    // optional (mean, rstd) per row
     long M; int C; float eps;
 };
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
                 o.z = (v[i].z - mean) * rstd * g.z + b.z;
                 o.w = (v[i].w - mean) * rstd * g.w + b.w;
                 store4(p.y, p.y_f32, row * p.C + c, o);
+                if (p.y16 != nullptr) store4(p.y16, 0, row * p.C + c, o);
             }
         }
     }
@@ -85,11 +87,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
 
 extern "C" int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtype, float* h_out,
                                   const float* gamma, const float* beta, void* y, int y_dtype, float* stats,
-                                  long M, int C, float eps, hipStream_t stream) {
+                                  long M, int C, float eps, void* y16, hipStream_t stream) {
     UENC_CHECK_ARG(x && gamma && beta && y && M > 0 && C > 0 && C % 4 == 0 && C <= 6144);
     LnFwd p;
     p.x = x; p.x_f32 = (x_dtype == UENC_F32); p.res = res; p.res_f32 = (res_dtype == UENC_F32);
-    p.h_out = h_out; p.gamma = gamma; p.beta = beta; p.y = y; p.y_f32 = (y_dtype == UENC_F32);
+    p.h_out = h_out; p.gamma = gamma; p.beta = beta; p.y = y; p.y_f32 = (y_dtype == UENC_F32); p.y16 = (bf16*)y16;
     p.stats = (float2*)stats; p.M = M; p.C = C; p.eps = eps;
     long blocks = (M + 3) / 4;
     if (blocks > 8192) blocks = 8192;
@@ -114,6 +116,7 @@ struct LnBwd {
     const float* gamma;
     const float* dres;               // optional fp32 gradient arriving on the skip path
     void* dx; int dx_f32;
+    bf16* dx16;                      // optional bf16 twin of dx (operand of the GEMMs that consume the gradient)
     float* dgamma; float* dbeta;     // accumulated (atomicAdd)
     long M; int C;
 };
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
                 store4(p.dx, p.dx_f32, row * p.C + c, o);
+                if (p.dx16 != nullptr) store4(p.dx16, 0, row * p.C + c, o);
             }
         }
     }
@@ -193,12 +197,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
 
 extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats,
                                   const float* gamma, const float* dres, void* dx, int dx_dtype, float* dgamma,
-                                  float* dbeta, long M, int C, hipStream_t stream) {
+                                  float* dbeta, long M, int C, void* dx16, hipStream_t stream) {
     UENC_CHECK_ARG(dy && h && stats && gamma && dx && M > 0 && C > 0 && C % 4 == 0 && C <= 6144);
     UENC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     LnBwd p;
     p.dy = dy; p.dy_f32 = (dy_dtype == UENC_F32); p.h = h; p.h_f32 = (h_dtype == UENC_F32);
-    p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32);
+    p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32); p.dx16 = (bf16*)dx16;
     p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C;
     long blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;

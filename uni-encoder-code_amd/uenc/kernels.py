@@ -89,8 +89,10 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[to
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, res: Optional[torch.Tensor] = None,
-                  out_dtype=torch.bfloat16, want_h: bool = False, want_stats: bool = True, eps: float = 1e-5):
-    """y = LN(x + res).  Returns (y, h, stats): h = x + res in fp32 if want_h, stats = (M, 2) (mean, rstd)."""
+                  out_dtype=torch.bfloat16, want_h: bool = False, want_stats: bool = True, eps: float = 1e-5,
+                  twin: Optional[list] = None):
+    """y = LN(x + res).  Returns (y, h, stats): h = x + res in fp32 if want_h, stats = (M, 2) (mean, rstd).
+    twin: a list that receives the bf16 copy of an fp32 y, written in the same pass."""
     C = x.shape[-1]
     assert x.is_cuda and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     M = x.numel() // C
@@ -99,24 +101,33 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, r
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if want_stats else None
     if res is not None:
         assert res.shape == x.shape and res.is_contiguous()
+    y16 = None
+    if twin is not None and out_dtype == torch.float32:
+        y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        twin.append(y16)
     check(lib.uenc_layernorm_fwd(x.data_ptr(), dt(x), ptr(res), dt(res) if res is not None else 0, ptr(h),
                                  gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), dt(y), ptr(stats), M, C, float(eps),
-                                 stream_ptr()), "layernorm_fwd")
+                                 ptr(y16), stream_ptr()), "layernorm_fwd")
     return y, h, stats
 
 
 def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, *,
                   dres: Optional[torch.Tensor] = None, dgamma: Optional[torch.Tensor] = None,
-                  dbeta: Optional[torch.Tensor] = None, dx_dtype=torch.float32) -> torch.Tensor:
-    """dx = LN'(dy) [+ dres]; dgamma / dbeta are accumulated in place (fp32)."""
+                  dbeta: Optional[torch.Tensor] = None, dx_dtype=torch.float32, twin: Optional[list] = None) -> torch.Tensor:
+    """dx = LN'(dy) [+ dres]; dgamma / dbeta are accumulated in place (fp32).  twin: a list that receives the bf16 copy of an
+    fp32 dx, written in the same pass."""
     C = h.shape[-1]
     M = h.numel() // C
     assert dy.is_contiguous() and h.is_contiguous() and dy.shape == h.shape
     dx = torch.empty(h.shape, dtype=dx_dtype, device=h.device)
     if dres is not None:
         assert dres.dtype == torch.float32 and dres.is_contiguous() and dres.shape == h.shape
+    dx16 = None
+    if twin is not None and dx_dtype == torch.float32:
+        dx16 = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+        twin.append(dx16)
     check(lib.uenc_layernorm_bwd(dy.data_ptr(), dt(dy), h.data_ptr(), dt(h), stats.data_ptr(), gamma.data_ptr(),
-                                 ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, stream_ptr()),
+                                 ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, ptr(dx16), stream_ptr()),
           "layernorm_bwd")
     return dx
 

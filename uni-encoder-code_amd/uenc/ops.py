@@ -269,9 +269,35 @@ def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.
 _BIG_M = 8192      # from this many rows on, an fp32 operand is first copied to bf16: the LDS-DMA GEMM kernels read bf16 only
 
 
+# bf16 twins: producers that stream an fp32 tensor out (LayerNorm forward / backward) can write its bf16 copy in the same
+# pass; consumers that need a bf16 GEMM operand ask here before launching a cast kernel.  Keyed by storage address, valid
+# while the producing tensor object lives and its version counter (shared with every view) has not moved -- an in-place
+# accumulation by the autograd engine into the fp32 tensor therefore drops the twin instead of leaving it stale.
+_TWINS = {}
+
+
+def _register_twin(t32: torch.Tensor, t16: torch.Tensor):
+    key = t32.data_ptr()
+
+    def _gone(_, key=key):
+        _TWINS.pop(key, None)
+    _TWINS[key] = (weakref.ref(t32, _gone), t32._version, t32.numel(), t16)
+
+
+def _twin(t: torch.Tensor) -> Optional[torch.Tensor]:
+    e = _TWINS.get(t.data_ptr())
+    if e is None or t.dtype != F32 or not t.is_contiguous():
+        return None
+    owner = e[0]()
+    if owner is None or owner._version != e[1] or t._version != e[1] or t.numel() != e[2]:
+        return None
+    return e[3].view(t.shape)
+
+
 def _as_bf16_operand(t2: torch.Tensor) -> torch.Tensor:
     if t2.dtype == F32 and t2.shape[0] >= _BIG_M and t2.is_contiguous() and t2.numel() % 8 == 0:
-        return K.cast_bf16(t2)
+        tw = _twin(t2)
+        return tw if tw is not None else K.cast_bf16(t2)
     return t2
 
 
@@ -437,7 +463,10 @@ class LayerNormFn(torch.autograd.Function):
         xc = x.contiguous()
         rc = res.contiguous() if res is not None else None
         need_h = rc is not None or xc.dtype != F32
-        y, h, stats = K.layernorm_fwd(xc, gamma.detach(), beta.detach(), res=rc, out_dtype=out_dtype, want_h=need_h, eps=eps)
+        tw = [] if (out_dtype == F32 and xc.numel() // xc.shape[-1] >= _BIG_M) else None
+        y, h, stats = K.layernorm_fwd(xc, gamma.detach(), beta.detach(), res=rc, out_dtype=out_dtype, want_h=need_h, eps=eps, twin=tw)
+        if tw:
+            _register_twin(y, tw[0])
         ctx.save_for_backward(h if need_h else xc, stats, gamma, beta)
         ctx.has_res, ctx.xdtype, ctx.rdtype = rc is not None, x.dtype, (res.dtype if res is not None else None)
         return y
@@ -447,7 +476,10 @@ class LayerNormFn(torch.autograd.Function):
         h, stats, gamma, beta = ctx.saved_tensors
         dg = grad_buf(gamma) if gamma.requires_grad else None
         db = grad_buf(beta) if gamma.requires_grad else None
-        dx = K.layernorm_bwd(dy.contiguous(), h, stats, gamma.detach(), dgamma=dg, dbeta=db)
+        tw = [] if h.numel() // h.shape[-1] >= _BIG_M else None
+        dx = K.layernorm_bwd(dy.contiguous(), h, stats, gamma.detach(), dgamma=dg, dbeta=db, twin=tw)
+        if tw:
+            _register_twin(dx, tw[0])
         _notify(gamma, beta)
         dxx = dx if ctx.xdtype == F32 else dx.to(ctx.xdtype)
         dr = None
@@ -500,17 +532,20 @@ class SwinBlockFn(torch.autograd.Function):
             d2 = d2.contiguous()
         train = wqkv.requires_grad
         # MLP branch (bf16 copy of the incoming stream gradient: the dgrad / wgrad GEMMs read bf16 operands)
-        d2h = K.cast_bf16(d2)
+        d2h = _twin(d2)                                     # written by the LayerNorm backward that produced this gradient
+        if d2h is None:
+            d2h = K.cast_bf16(d2)
         dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)             # (M, 4C) d(pre-GELU)
         if train:
             _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
         dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))                                              # (M, C)
         if train:
             _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
+        tw = []
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
-                              dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None)
+                              dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
         # attention branch
-        dx1h = K.cast_bf16(dx1)
+        dx1h = tw[0]
         dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))                                        # (M, C) bf16
         if train:
             _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
@@ -522,8 +557,10 @@ class SwinBlockFn(torch.autograd.Function):
             grad_buf(bqkv).add_(dpad)
             grad_buf(table).add_(dtab.t())
             _tn(dqkv2, xn, grad_buf(wqkv), grad_buf(bqkv), (wqkv, bqkv))
+        tw = []
         dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
-                             dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None)
+                             dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None, twin=tw)
+        _register_twin(dx, tw[0])                           # the previous block's backward starts from dx in bf16
         if train:
             _tn_notify(g1, b1, table, g2, b2)
         return (dx.view(B, L, C),) + (None,) * 19
