@@ -58,6 +58,22 @@ int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi,
  * logits fp32 [rows][Hi][Wi]; mask u8 [rows][Ho][Wo]. */
 int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, void* stream);
 
+/* ---- glue of the deformable encoder layer (pixel_decoder/ops/modules/ms_deform_attn.py:91-113) ---------------------
+ * out = bf16(a + b), b repeating every `period` elements (n % period == 0, both % 4 == 0): query = src + pos. */
+int uenc_add_cast_bf16(const float* a, const float* b, void* out, long n, long period, void* stream);
+/* offaw (rows, ld) fp32 = [M][L][P][2] sampling offsets | [M][L*P] attention logits per row (row = image * Lq + query):
+ * loc (rows, M, L, P, 2) = ref + off / (W_l, H_l), aw (rows, M, L*P) = softmax(logits).  ref (N|1, Lq, L, 2) fp32
+ * (ref_per_image: 1 if it has a batch dimension), shapes (L, 2) int64 device.  L * P <= 16. */
+int uenc_msda_prep_fwd(const float* offaw, long ld, const float* ref, int ref_per_image, const int64_t* shapes, float* loc,
+                       float* aw, long rows, int Lq, int M, int L, int P, void* stream);
+/* doffaw (rows, ld) bf16 <- d(loc), d(aw) and the saved softmax aw. */
+int uenc_msda_prep_bwd(const float* dloc, const float* daw, const float* aw, const int64_t* shapes, void* doffaw, long ld,
+                       long rows, int Lq, int M, int L, int P, void* stream);
+/* out (nseg, cols) fp32 += column sums of the bf16 matrix x16 over row segments [seg_start[s], seg_start[s+1]) of every
+ * image (rows_per_image rows each): per-level sums for the level-embedding gradient. */
+int uenc_segment_colsum(const void* x16, long ld, int cols, const int64_t* seg_start, int nseg, long rows_per_image, int images,
+                        float* out, void* stream);
+
 /* ---- FPN branch of the pixel decoder on token matrices (pixel_decoder/msdeformattn.py:283-304, :343-352) -----------
  * y = GroupNorm(x) [+ bilinear_resize(add_src, align_corners=False)] [ReLU] for x, y (B, HW, C) fp32|bf16 (torch.nn.GroupNorm
  * semantics over (HW x C/G) per image and group).  stats (B, G, 2) = (mean, rstd) is written for the backward; scratch:

@@ -358,3 +358,30 @@ def test_attn_mask_matches_torch(K):
         # a different rounding of the 4-tap sum may flip the sign only where the resized logit is ~0
         assert (am.flatten(2)[diff].abs() < 1e-6).all() and diff.float().mean() < 1e-4
         assert not got[0, 2].any()
+
+
+@pytest.mark.parametrize("L,P", [(3, 4), (2, 3)])
+def test_msda_prep_kernels(K, L, P):
+    """softmax + sampling-location arithmetic of MSDeformAttn.forward (ms_deform_attn.py:98-106) and its adjoint."""
+    B, Lq, M = 2, 37, 8
+    LP = L * P
+    ld = 3 * M * LP
+    g = torch.Generator().manual_seed(2)
+    offaw = torch.randn(B * Lq, ld, generator=g).cuda().requires_grad_()
+    ref = torch.rand(1, Lq, L, 2, generator=g).cuda()
+    shapes = torch.tensor([(5 + 3 * l, 7 + 5 * l) for l in range(L)], dtype=torch.int64).cuda()
+    loc, aw = K.msda_prep_fwd(offaw.detach(), ref, shapes, B, Lq, M, L, P)
+    off = offaw[:, :2 * M * LP].view(B, Lq, M, L, P, 2)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    loc2 = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw2 = offaw[:, 2 * M * LP:].view(B, Lq, M, LP).softmax(-1).view(B, Lq, M, L, P)
+    _close(loc, loc2, 1e-6, 1e-5); _close(aw, aw2, 1e-6, 1e-5)
+    dloc, daw = torch.randn(loc.shape, generator=g).cuda(), torch.randn(aw.shape, generator=g).cuda()
+    ((loc2 * dloc).sum() + (aw2 * daw).sum()).backward()
+    got = K.msda_prep_bwd(dloc, daw, aw, shapes, ld)
+    _close(got, offaw.grad, 2e-2 * float(offaw.grad.abs().max()), 1e-2)
+    start = torch.tensor([0, 11, 30][:L] if L == 3 else [0, 20], dtype=torch.int64).cuda()
+    sums = K.segment_colsum(got, start, Lq, B)
+    want = torch.stack([got.float().view(B, Lq, ld)[:, int(start[s]):(int(start[s + 1]) if s + 1 < len(start) else Lq)].sum((0, 1))
+                        for s in range(len(start))])
+    _close(sums, want, 1e-3 * float(want.abs().max()), 1e-3)

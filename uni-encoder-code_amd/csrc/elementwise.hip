@@ -181,3 +181,208 @@ extern "C" int uenc_cast_multi(const void* table, int n, long total_tiles, hipSt
 
 extern "C" int uenc_version(void) { return 1; }
 extern "C" const char* uenc_arch(void) { return "gfx950"; }
+
+
+// ---- glue of the deformable encoder layer (pixel_decoder/ops/modules/ms_deform_attn.py:91-113) as three small kernels ----
+// out16 = bf16(a + b), b repeating every `period` elements (period == n: same shape): the query = src + pos operand of
+// the sampling-offset / attention-weight GEMM, without materialising the fp32 sum.
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16* __restrict__ out,
+                                                       long n4, long period4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i % period4];
+        bf16x4 o; o[0] = (bf16)(x.x + y.x); o[1] = (bf16)(x.y + y.y); o[2] = (bf16)(x.z + y.z); o[3] = (bf16)(x.w + y.w);
+        ((bf16x4*)out)[i] = o;
+    }
+}
+
+extern "C" int uenc_add_cast_bf16(const float* a, const float* b, void* out, long n, long period, hipStream_t stream) {
+    UENC_CHECK_ARG(a && b && out && n > 0 && period > 0 && n % 4 == 0 && period % 4 == 0 && n % period == 0);
+    UENC_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0 && ((uintptr_t)out & 7) == 0);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, b, (bf16*)out, n / 4, period / 4);
+    UENC_LAUNCH_RET();
+}
+
+// One thread per (row = image * Lq + query, head).  offaw: (rows, ld) fp32, columns [M][L][P][2] sampling offsets then
+// [M][L*P] attention logits (the output of one GEMM over the concatenated weights).
+//   loc[row][m][l][p][:] = ref[row or query][l][:] + off / (W_l, H_l)        (ms_deform_attn.py:103-106)
+//   aw [row][m][:]       = softmax over the L*P logits                       (:101)
+struct PrepP {
+    const float* offaw; long ld;
+    const float* ref; int ref_per_image;       // (N|1, Lq, L, 2)
+    const int64_t* shapes;                     // (L, 2) H, W
+    float* loc; float* aw;                     // forward outputs / backward: aw = saved softmax
+    const float* dloc; const float* daw;       // backward inputs
+    bf16* doffaw;                              // backward output (rows, ld) bf16
+    long rows; int Lq, M, L, P;
+};
+
+// LPQ = L * P / 4 (> 0): every per-(row, head) vector is moved as 16-byte pieces held in registers; LPQ = 0: generic scalar form.
+template <bool BWD, int LPQ>
+__global__ __launch_bounds__(256) void msda_prep_kernel(PrepP p) {
+    const long total = p.rows * p.M;
+    const int LP = LPQ > 0 ? LPQ * 4 : p.L * p.P;
+    constexpr int NV = LPQ > 0 ? LPQ * 4 : 16;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long row = t / p.M;
+        const int m = (int)(t - row * p.M);
+        const long o_off = row * p.ld + (long)m * LP * 2, o_lg = row * p.ld + (long)p.M * LP * 2 + (long)m * LP;
+        float v[2 * NV], w[NV], a[NV];       // offsets or d(loc); logits or d(aw); softmax
+        if (!BWD) {
+            if (LPQ > 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * LPQ; ++i) *(float4*)(v + 4 * i) = *(const float4*)(p.offaw + o_off + 4 * i);
+#pragma unroll
+                for (int i = 0; i < LPQ; ++i) *(float4*)(w + 4 * i) = *(const float4*)(p.offaw + o_lg + 4 * i);
+            } else {
+                for (int j = 0; j < NV; ++j) { w[j] = j < LP ? p.offaw[o_lg + j] : -3.0e38f; v[2 * j] = j < LP ? p.offaw[o_off + 2 * j] : 0.f; v[2 * j + 1] = j < LP ? p.offaw[o_off + 2 * j + 1] : 0.f; }
+            }
+            const long q = p.ref_per_image ? row : row % p.Lq;
+            const float* rf = p.ref + q * p.L * 2;
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) if (j < LP) mx = fmaxf(mx, w[j]);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { w[j] = j < LP ? __expf(w[j] - mx) : 0.f; sum += w[j]; }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                w[j] *= inv;
+                if (j < LP) {
+                    const int l = j / p.P;
+                    v[2 * j] = rf[2 * l] + v[2 * j] / (float)p.shapes[2 * l + 1];
+                    v[2 * j + 1] = rf[2 * l + 1] + v[2 * j + 1] / (float)p.shapes[2 * l];
+                }
+            }
+            if (LPQ > 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * LPQ; ++i) *(float4*)(p.loc + t * LP * 2 + 4 * i) = *(const float4*)(v + 4 * i);
+#pragma unroll
+                for (int i = 0; i < LPQ; ++i) *(float4*)(p.aw + t * LP + 4 * i) = *(const float4*)(w + 4 * i);
+            } else {
+                for (int j = 0; j < LP; ++j) { p.aw[t * LP + j] = w[j]; p.loc[t * LP * 2 + 2 * j] = v[2 * j]; p.loc[t * LP * 2 + 2 * j + 1] = v[2 * j + 1]; }
+            }
+        } else {
+            if (LPQ > 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * LPQ; ++i) *(float4*)(v + 4 * i) = *(const float4*)(p.dloc + t * LP * 2 + 4 * i);
+#pragma unroll
+                for (int i = 0; i < LPQ; ++i) { *(float4*)(w + 4 * i) = *(const float4*)(p.daw + t * LP + 4 * i); *(float4*)(a + 4 * i) = *(const float4*)(p.aw + t * LP + 4 * i); }
+            } else {
+                for (int j = 0; j < NV; ++j) {
+                    w[j] = j < LP ? p.daw[t * LP + j] : 0.f; a[j] = j < LP ? p.aw[t * LP + j] : 0.f;
+                    v[2 * j] = j < LP ? p.dloc[t * LP * 2 + 2 * j] : 0.f; v[2 * j + 1] = j < LP ? p.dloc[t * LP * 2 + 2 * j + 1] : 0.f;
+                }
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) dot += a[j] * w[j];
+            bf16 dof[2 * NV], dlg[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int l = j < LP ? j / p.P : 0;
+                dof[2 * j] = (bf16)(v[2 * j] / (float)p.shapes[2 * l + 1]);
+                dof[2 * j + 1] = (bf16)(v[2 * j + 1] / (float)p.shapes[2 * l]);
+                dlg[j] = (bf16)(a[j] * (w[j] - dot));
+            }
+            if (LPQ > 0) {
+#pragma unroll
+                for (int i = 0; i < LPQ; ++i) {
+                    *(bf16x8*)(p.doffaw + o_off + 8 * i) = *(const bf16x8*)(dof + 8 * i);
+                    *(bf16x4*)(p.doffaw + o_lg + 4 * i) = *(const bf16x4*)(dlg + 4 * i);
+                }
+            } else {
+                for (int j = 0; j < LP; ++j) { p.doffaw[o_off + 2 * j] = dof[2 * j]; p.doffaw[o_off + 2 * j + 1] = dof[2 * j + 1]; p.doffaw[o_lg + j] = dlg[j]; }
+            }
+        }
+    }
+}
+
+template <bool BWD>
+static void prep_launch(const PrepP& p, hipStream_t stream) {
+    long blocks = (p.rows * p.M + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const int LP = p.L * p.P;
+    const bool vec = LP % 4 == 0 && p.ld % 8 == 0;       // 16-byte pieces stay aligned
+    dim3 g((unsigned)blocks), b(256);
+    if (vec && LP == 4) hipLaunchKernelGGL((msda_prep_kernel<BWD, 1>), g, b, 0, stream, p);
+    else if (vec && LP == 8) hipLaunchKernelGGL((msda_prep_kernel<BWD, 2>), g, b, 0, stream, p);
+    else if (vec && LP == 12) hipLaunchKernelGGL((msda_prep_kernel<BWD, 3>), g, b, 0, stream, p);
+    else if (vec && LP == 16) hipLaunchKernelGGL((msda_prep_kernel<BWD, 4>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((msda_prep_kernel<BWD, 0>), g, b, 0, stream, p);
+}
+
+static int prep_fill(PrepP& p, const float* ref, int ref_per_image, const int64_t* shapes, long rows, int Lq, int M, int L, int P, long ld) {
+    if (!(ref && shapes && rows > 0 && Lq > 0 && M > 0 && L > 0 && P > 0 && L * P <= 16 && ld >= (long)M * L * P * 3)) return UENC_EINVAL;
+    p.ref = ref; p.ref_per_image = ref_per_image; p.shapes = shapes; p.rows = rows; p.Lq = Lq; p.M = M; p.L = L; p.P = P; p.ld = ld;
+    p.offaw = nullptr; p.loc = p.aw = nullptr; p.dloc = p.daw = nullptr; p.doffaw = nullptr;
+    return UENC_OK;
+}
+
+extern "C" int uenc_msda_prep_fwd(const float* offaw, long ld, const float* ref, int ref_per_image, const int64_t* shapes, float* loc,
+                                  float* aw, long rows, int Lq, int M, int L, int P, hipStream_t stream) {
+    PrepP p;
+    int rc = prep_fill(p, ref, ref_per_image, shapes, rows, Lq, M, L, P, ld);
+    if (rc != UENC_OK) return rc;
+    UENC_CHECK_ARG(offaw && loc && aw);
+    UENC_CHECK_ARG((((uintptr_t)offaw | (uintptr_t)loc | (uintptr_t)aw) & 15) == 0);
+    p.offaw = offaw; p.loc = loc; p.aw = aw;
+    prep_launch<false>(p, stream);
+    UENC_LAUNCH_RET();
+}
+
+// d(offaw) in bf16 (the dgrad / wgrad GEMM operand) from d(loc), d(softmaxed weights) and the saved softmax.
+extern "C" int uenc_msda_prep_bwd(const float* dloc, const float* daw, const float* aw, const int64_t* shapes, void* doffaw, long ld,
+                                  long rows, int Lq, int M, int L, int P, hipStream_t stream) {
+    PrepP p;
+    int rc = prep_fill(p, dloc, 0, shapes, rows, Lq, M, L, P, ld);
+    if (rc != UENC_OK) return rc;
+    UENC_CHECK_ARG(dloc && daw && aw && doffaw);
+    UENC_CHECK_ARG((((uintptr_t)dloc | (uintptr_t)daw | (uintptr_t)aw | (uintptr_t)doffaw) & 15) == 0);
+    p.dloc = dloc; p.daw = daw; p.aw = (float*)aw; p.doffaw = (bf16*)doffaw;
+    prep_launch<true>(p, stream);
+    UENC_LAUNCH_RET();
+}
+
+// out[seg][c] += sum over rows [seg_start[seg], seg_start[seg + 1]) of every image of x16[row][c]: the per-level column sums
+// that give the level-embedding gradient (level_embed enters the query through pos, msdeformattn.py:104-113).
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const bf16* __restrict__ x, long ld, int cols, const int64_t* __restrict__ seg_start,
+                                                             int nseg, long rows_per_image, int images, float* __restrict__ out) {
+    // thread = (8-column group cg, row lane r); 16-byte loads; the block's partial goes to `out` by one atomic per column
+    __shared__ float red[256][8];
+    const int seg = blockIdx.y;
+    const long s0 = seg_start[seg], s1 = seg + 1 < nseg ? (long)seg_start[seg + 1] : rows_per_image;
+    const long len = s1 - s0, n = len * images;
+    const int ncg = cols >> 3, nr = 256 / ncg;
+    const int cg = threadIdx.x % ncg, r = threadIdx.x / ncg;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < nr)
+        for (long i = (long)blockIdx.x * nr + r; i < n; i += (long)gridDim.x * nr) {
+            const long img = i / len, row = s0 + (i - img * len);
+            const bf16x8 v = *(const bf16x8*)(x + (img * rows_per_image + row) * ld + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = r < nr ? acc[j] : 0.f;
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            for (int rr = 0; rr < nr; ++rr) v += red[cg + rr * ncg][j];
+            atomicAdd(out + (long)seg * cols + cg * 8 + j, v);
+        }
+    }
+}
+
+extern "C" int uenc_segment_colsum(const void* x16, long ld, int cols, const int64_t* seg_start, int nseg, long rows_per_image, int images,
+                                   float* out, hipStream_t stream) {
+    UENC_CHECK_ARG(x16 && seg_start && out && cols > 0 && nseg > 0 && rows_per_image > 0 && images > 0 && ld >= cols);
+    UENC_CHECK_ARG(cols % 8 == 0 && cols <= 2048 && ld % 8 == 0 && ((uintptr_t)x16 & 15) == 0);
+    hipLaunchKernelGGL(segment_colsum_kernel, dim3(256, nseg), dim3(256), 0, stream, (const bf16*)x16, ld, cols, seg_start, nseg,
+                       rows_per_image, images, out);
+    UENC_LAUNCH_RET();
+}

@@ -34,6 +34,10 @@ _SIGNATURES = {
     "uenc_upsample_bilinear_tokens_bwd": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_im2col3x3": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_col2im3x3": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "uenc_add_cast_bf16": [c_p, c_p, c_p, c_l, c_l, c_p],
+    "uenc_msda_prep_fwd": [c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
+    "uenc_msda_prep_bwd": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p],
+    "uenc_segment_colsum": [c_p, c_l, c_i, c_p, c_i, c_l, c_i, c_p, c_p],
     "uenc_gemm_tn": [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_tn_grouped": [c_p, c_i, c_i, c_i, ctypes.c_double, c_p],
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p, c_p],

@@ -316,3 +316,44 @@ def col2im3x3(dcol, B: int, H: int, W: int, C: int):
     dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dcol.device)
     check(lib.uenc_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "col2im3x3")
     return dx
+
+
+# --------------------------------------------------------------------------------------------
+# deformable encoder layer glue
+# --------------------------------------------------------------------------------------------
+def add_cast_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bf16(a + b); b may be one period of a (e.g. (S, C) against (B, S, C))."""
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
+    check(lib.uenc_add_cast_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), stream_ptr()), "add_cast_bf16")
+    return out
+
+
+def msda_prep_fwd(offaw: torch.Tensor, ref: torch.Tensor, shapes: torch.Tensor, B: int, Lq: int, M: int, L: int, P: int):
+    """offaw (B*Lq, >= 3*M*L*P) fp32 -> loc (B, Lq, M, L, P, 2), aw (B, Lq, M, L, P) (softmaxed)."""
+    assert offaw.dtype == torch.float32 and offaw.stride(1) == 1 and ref.dtype == torch.float32 and ref.is_contiguous()
+    loc = torch.empty((B, Lq, M, L, P, 2), dtype=torch.float32, device=offaw.device)
+    aw = torch.empty((B, Lq, M, L, P), dtype=torch.float32, device=offaw.device)
+    check(lib.uenc_msda_prep_fwd(offaw.data_ptr(), offaw.stride(0), ref.data_ptr(), int(ref.shape[0] != 1), shapes.data_ptr(),
+                                 loc.data_ptr(), aw.data_ptr(), B * Lq, Lq, M, L, P, stream_ptr()), "msda_prep_fwd")
+    return loc, aw
+
+
+def msda_prep_bwd(dloc, daw, aw, shapes, ncols: int):
+    """-> d(offaw) (B*Lq, ncols) bf16."""
+    B, Lq, M, L, P, _ = dloc.shape
+    assert dloc.is_contiguous() and daw.is_contiguous() and aw.is_contiguous() and ncols == 3 * M * L * P
+    out = torch.empty((B * Lq, ncols), dtype=torch.bfloat16, device=dloc.device)
+    check(lib.uenc_msda_prep_bwd(dloc.data_ptr(), daw.data_ptr(), aw.data_ptr(), shapes.data_ptr(), out.data_ptr(), ncols, B * Lq, Lq,
+                                 M, L, P, stream_ptr()), "msda_prep_bwd")
+    return out
+
+
+def segment_colsum(x16: torch.Tensor, seg_start: torch.Tensor, rows_per_image: int, images: int) -> torch.Tensor:
+    """x16 (images * rows_per_image, cols) bf16 -> (nseg, cols) fp32 sums over the row segments of every image."""
+    assert x16.dtype == torch.bfloat16 and x16.stride(1) == 1 and seg_start.dtype == torch.int64
+    nseg, cols = seg_start.numel(), x16.shape[1]
+    out = torch.zeros((nseg, cols), dtype=torch.float32, device=x16.device)
+    check(lib.uenc_segment_colsum(x16.data_ptr(), x16.stride(0), cols, seg_start.data_ptr(), nseg, rows_per_image, images, out.data_ptr(),
+                                  stream_ptr()), "segment_colsum")
+    return out

@@ -58,7 +58,18 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, level_embed=None):
+        a = self.self_attn
+        if (level_embed is not None and pos is not None and padding_mask is None and reference_points.shape[-1] == 2
+                and a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16):
+            # the whole layer as one autograd node (ops.DeformEncoderLayerFn); `pos` is then a constant and the gradient of
+            # the level embedding inside it is returned through `level_embed`
+            return ops.deform_encoder_layer(
+                src, pos, level_embed, reference_points, spatial_shapes, level_start_index, a.n_heads, a.n_points,
+                [a.value_proj.weight, a.value_proj.bias, a.sampling_offsets.weight, a.sampling_offsets.bias,
+                 a.attention_weights.weight, a.attention_weights.bias, a.output_proj.weight, a.output_proj.bias,
+                 self.norm1.weight, self.norm1.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                 self.norm2.weight, self.norm2.bias])
         q = src if pos is None else src + pos
         h = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask, residual=src)
         src = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)
@@ -85,12 +96,13 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         ref = torch.cat(pts, 1)
         return ref[:, :, None] * valid_ratios[:, None]
 
-    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, shapes_list=None, ref=None):
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, shapes_list=None, ref=None,
+                level_embed=None):
         out = src
         if ref is None:
             ref = self.get_reference_points(shapes_list, valid_ratios, src.device).contiguous()
         for layer in self.layers:
-            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, level_embed)
         return out
 
 
@@ -116,7 +128,15 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         device = srcs_tok[0].device
         B = srcs_tok[0].shape[0]
         src = torch.cat(srcs_tok, 1)
-        pos = torch.cat([p + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_tok)], 1)
+        a = self.encoder.layers[0].self_attn
+        fused = a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16
+        if fused:
+            # pos = sine embedding + level embedding: a constant map for the fused layers (one period (S, C), shared by the
+            # batch), which return the level embedding's gradient themselves
+            with torch.no_grad():
+                pos = torch.cat([p[:1] + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_tok)], 1)
+        else:
+            pos = torch.cat([p + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_tok)], 1)
         key = (tuple(shapes_list), B, str(device))
         geo = self._geometry.get(key)
         if geo is None:       # level geometry lives on the device; built once per shape (no per-step host-to-device copies)
@@ -127,7 +147,8 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             geo = (spatial_shapes, level_start_index, valid_ratios, ref)
             self._geometry[key] = geo
         spatial_shapes, level_start_index, valid_ratios, ref = geo
-        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None, shapes_list, ref)
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, None, shapes_list, ref,
+                              self.level_embed if fused else None)
         return memory, spatial_shapes, level_start_index, valid_ratios
 
 

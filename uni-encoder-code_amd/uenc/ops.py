@@ -80,6 +80,30 @@ class ParamCache:
         plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 1) if aligned else None
         return self._get(p, ("t", rows), make, plan)
 
+    def _get2(self, p1, p2, kind, make):
+        """Like _get for an operand derived from two parameters (valid while neither changed)."""
+        key = (id(p1), (kind, id(p2)))
+        ent = self._store.get(key)
+        sig = (p1._version, p1.data_ptr(), p2._version, p2.data_ptr())
+        if ent is not None and ent[3]() is p1 and ent[5]() is p2 and ent[0] == sig:
+            return ent[2]
+        t = make()
+        self.casts += 1
+        self._store[key] = (sig, p1.data_ptr(), t, weakref.ref(p1), None, weakref.ref(p2))
+        self._table = None
+        return t
+
+    def cat(self, p1: torch.Tensor, p2: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+        """bf16 [p1; p2] stacked along the output dimension ((N1+N2, K), or its (K, N1+N2) transpose): two Linear layers that
+        read the same input run as one GEMM."""
+        def make():
+            w = torch.cat([p1.detach().reshape(p1.shape[0], -1), p2.detach().reshape(p2.shape[0], -1)], 0).contiguous()
+            return K.cast_transpose_bf16(w) if transposed else K.cast_bf16(w)
+        return self._get2(p1, p2, "catT" if transposed else "cat", make)
+
+    def catvec(self, p1: torch.Tensor, p2: torch.Tensor) -> torch.Tensor:
+        return self._get2(p1, p2, "catv", lambda: torch.cat([p1.detach(), p2.detach()]).float().contiguous())
+
     def vec16(self, p: torch.Tensor) -> torch.Tensor:
         return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()), (0, 1, p.numel(), 0))
 
@@ -568,6 +592,103 @@ class SwinBlockFn(torch.autograd.Function):
 
 def swin_block(x, H, W, ws, shift, nH, scale, params: Sequence[torch.Tensor]):
     return SwinBlockFn.apply(x, H, W, ws, shift, nH, scale, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# One whole deformable-attention encoder layer (reference pixel_decoder/msdeformattn.py:103-142 with
+# ops/modules/ms_deform_attn.py:74-113) as one autograd node: 10 kernels forward, explicit backward.
+# --------------------------------------------------------------------------------------------
+class DeformEncoderLayerFn(torch.autograd.Function):
+    """src (B, S, C) fp32 stream -> LN2(src1 + FFN(src1)),  src1 = LN1(src + MSDeformAttn(src + pos, src)).
+
+    What the module-by-module form spends on glue disappears here: query = bf16(src + pos) is one kernel, sampling offsets
+    and attention logits come from ONE GEMM over the stacked weights, softmax + sampling-location arithmetic is one small
+    kernel each way, every residual / skip-path sum rides in a GEMM or LayerNorm epilogue (no elementwise adds), the
+    LayerNorms hand their results on in fp32 and bf16 at once (no casts), and the gradient of the level embedding (which
+    enters through pos) is taken from per-level column sums of the offset/logit gradient instead of a (B, S, C) map.
+    """
+
+    @staticmethod
+    def forward(ctx, src, pos, level_embed, ref, shapes, level_start, nH, nP,
+                wv, bv, woff, boff, waw, baw, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2):
+        B, S, C = src.shape
+        M, L, D = B * S, shapes.shape[0], C // nH
+        x = src.reshape(M, C)
+        x = x if x.is_contiguous() else x.contiguous()
+        x16 = _twin(x)
+        if x16 is None:
+            x16 = K.cast_bf16(x)
+        posc = pos.detach()
+        posc = posc if posc.is_contiguous() else posc.contiguous()
+        q16 = K.add_cast_bf16(x, posc.reshape(-1, C))
+        value = K.gemm_nt(x16, CACHE.mat(wv), bias=bv.detach())                                   # (M, C) bf16
+        offaw = K.gemm_nt(q16, CACHE.cat(woff, waw), bias=CACHE.catvec(boff, baw), out_dtype=F32)   # (M, 3 nH L P) fp32
+        loc, aw = K.msda_prep_fwd(offaw, ref, shapes, B, S, nH, L, nP)
+        att = K.msdeform_attn_fwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, out_dtype=BF16).view(M, C)
+        h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
+        tw = []
+        s1, _, st1 = K.layernorm_fwd(h1, g1.detach(), b1.detach(), out_dtype=F32, twin=tw)
+        s1_16 = tw[0]
+        f = K.gemm_nt(s1_16, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_RELU)                # (M, ffn) bf16
+        h2 = K.gemm_nt(f, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=s1, out_dtype=F32)
+        tw = []
+        out, _, st2 = K.layernorm_fwd(h2, g2.detach(), b2.detach(), out_dtype=F32, twin=tw)
+        _register_twin(out, tw[0])                                                                 # the next layer's value / query operand source
+        ctx.save_for_backward(x16, q16, value, loc, aw, att, h1, st1, s1_16, f, h2, st2, shapes, level_start,
+                              wv, bv, woff, boff, waw, baw, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2)
+        ctx.geom = (B, S, C, nH, nP)
+        ctx.shapes_host = _host_shapes(shapes)
+        return out.view(B, S, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x16, q16, value, loc, aw, att, h1, st1, s1_16, f, h2, st2, shapes, level_start,
+         wv, bv, woff, boff, waw, baw, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = ctx.saved_tensors
+        B, S, C, nH, nP = ctx.geom
+        M, L, D = B * S, shapes.shape[0], C // nH
+        train = wv.requires_grad
+        dy = dout.reshape(M, C)
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        gb = (lambda p: grad_buf(p)) if train else (lambda p: None)
+        # FFN block
+        tw = []
+        dh2 = K.layernorm_bwd(dy, h2, st2, g2.detach(), dgamma=gb(g2), dbeta=gb(b2), twin=tw)       # also the skip-path gradient of s1
+        dh2_16 = tw[0]
+        df = K.gemm_nt(dh2_16, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DRELU, aux=f)                    # (M, ffn) bf16
+        ds1 = K.gemm_nt(df, CACHE.mat_t(w1), epilogue=K.EPI_RESIDUAL, aux=dh2, out_dtype=F32)      # dh2 + dFFN-in
+        if train:
+            _tn(dh2_16, f, grad_buf(w2), grad_buf(bb2), (w2, bb2))
+            _tn(df, s1_16, grad_buf(w1), grad_buf(bb1), (w1, bb1))
+        # attention block
+        tw = []
+        dh1 = K.layernorm_bwd(ds1, h1, st1, g1.detach(), dgamma=gb(g1), dbeta=gb(b1), twin=tw)      # also the skip-path gradient of src
+        dh1_16 = tw[0]
+        datt = K.gemm_nt(dh1_16, CACHE.mat_t(wo))                                                  # (M, C) bf16
+        if train:
+            _tn(dh1_16, att, grad_buf(wo), grad_buf(bo), (wo, bo))
+        gv, gl, ga = K.msdeform_attn_bwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, datt.view(B, S, C), ctx.shapes_host)
+        ncol = 3 * nH * L * nP
+        doffaw = K.msda_prep_bwd(gl, ga, aw, shapes, ncol)                                         # (M, ncol) bf16
+        gv16 = K.cast_bf16(gv.view(M, C))
+        dsrc = K.gemm_nt(doffaw, CACHE.cat(woff, waw, transposed=True), epilogue=K.EPI_RESIDUAL, aux=dh1, out_dtype=F32)
+        dsrc = K.gemm_nt(gv16, CACHE.mat_t(wv), epilogue=K.EPI_RESIDUAL, aux=dsrc, out=dsrc)        # dh1 + dq + dvalue-in
+        dlev = None
+        if train:
+            no = 2 * nH * L * nP
+            _tn(doffaw[:, :no], q16, grad_buf(woff), grad_buf(boff), (woff, boff))
+            _tn(doffaw[:, no:], q16, grad_buf(waw), grad_buf(baw), (waw, baw))
+            _tn(gv16, x16, grad_buf(wv), grad_buf(bv), (wv, bv))
+            _tn_notify(g1, b1, g2, b2)
+        if ctx.needs_input_grad[2]:
+            # d level_embed[l] = sum over the level's tokens of dq = (per-level column sums of doffaw) @ [Woff; Waw]
+            sums = K.segment_colsum(doffaw, level_start, S, B)                                      # (L, ncol) fp32
+            wcat = torch.cat([woff.detach().reshape(woff.shape[0], -1), waw.detach().reshape(waw.shape[0], -1)], 0)
+            dlev = sums @ wcat
+        return (dsrc.view(B, S, C), None, dlev, None, None, None, None, None) + (None,) * 16
+
+
+def deform_encoder_layer(src, pos, level_embed, ref, shapes, level_start, nH, nP, params: Sequence[torch.Tensor]):
+    return DeformEncoderLayerFn.apply(src, pos, level_embed, ref, shapes, level_start, nH, nP, *params)
 
 
 # --------------------------------------------------------------------------------------------
