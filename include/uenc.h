@@ -132,10 +132,11 @@ int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtyp
                        void* stream);
 /* dx = LN'(dy) [+ dres];  dgamma / dbeta accumulated (both NULL to skip).
  * y16 / dx16 (may be NULL): a bf16 copy of y / dx written in the same pass -- the operand the next GEMM reads, so that an
- * fp32 stream needs no separate cast kernel. */
+ * fp32 stream needs no separate cast kernel.  part_ws (may be NULL): scratch of 2048 * 2 * C floats; with it the
+ * workgroups' dgamma / dbeta partials are stored and summed by a second small kernel instead of added atomically. */
 int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats, const float* gamma,
                        const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* dx16,
-                       void* stream);
+                       float* part_ws, void* stream);
 
 /* ---- shifted-window attention (head_dim 32, window <= 12) ---------------------------------------------
  * Replaces F.pad -> torch.roll -> window_partition -> WindowAttention core -> window_reverse -> roll -> crop,

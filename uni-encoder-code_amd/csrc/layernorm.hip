@@ -117,19 +117,18 @@ struct LnBwd {
     const float* dres;               // optional fp32 gradient arriving on the skip path
     void* dx; int dx_f32;
     bf16* dx16;                      // optional bf16 twin of dx (operand of the GEMMs that consume the gradient)
-    float* dgamma; float* dbeta;     // accumulated (atomicAdd)
+    float* dgamma; float* dbeta;     // accumulated
+    float* part;                     // optional (gridDim.x, 2, C) block partials of dgamma / dbeta (then summed by ln_bwd_param_kernel)
     long M; int C;
 };
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // [2][C] block partials of dgamma / dbeta
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][C] partials of dgamma / dbeta
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
     const float invC = 1.0f / (float)p.C;
-    for (int c = threadIdx.x; c < 2 * p.C; c += 256) sh[c] = 0.f;
-    __syncthreads();
     float4 ag[NV], ab[NV], gm[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -176,7 +175,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
             }
         }
     }
-    if (p.dgamma != nullptr) {
+    if (p.dgamma != nullptr && p.C > 2048) {            // wide rows: one [2][C] slab, LDS atomics (4 slabs would not fit)
+        for (int c = threadIdx.x; c < 2 * p.C; c += 256) sh[c] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
@@ -188,16 +189,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
             }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < p.C; c += 256) {   // 256 contiguous bytes per wave-instruction
-            atomicAdd(p.dgamma + c, sh[c]);
-            atomicAdd(p.dbeta + c, sh[p.C + c]);
+        for (int c = threadIdx.x; c < 2 * p.C; c += 256) {
+            if (p.part != nullptr) p.part[(long)blockIdx.x * 2 * p.C + c] = sh[c];
+            else atomicAdd((c < p.C ? p.dgamma + c : p.dbeta + (c - p.C)), sh[c]);
         }
+    } else if (p.dgamma != nullptr) {
+        // block partial: each wave parks its sums in its own LDS slab (plain 16-byte stores; LDS float atomics cost ~3 cycles
+        // per lane), the slabs are added while being written out
+        const int wv = threadIdx.x >> 6;
+        float* mine = sh + (long)wv * 2 * p.C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < p.C) { *(float4*)(mine + c) = ag[i]; *(float4*)(mine + p.C + c) = ab[i]; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * p.C; c += 256) {
+            const float v = sh[c] + sh[2 * p.C + c] + sh[4 * p.C + c] + sh[6 * p.C + c];
+            if (p.part != nullptr) p.part[(long)blockIdx.x * 2 * p.C + c] = v;          // one small kernel sums the blocks
+            else atomicAdd((c < p.C ? p.dgamma + c : p.dbeta + (c - p.C)), v);
+        }
+    }
+}
+
+// dgamma[c] += sum_b part[b][0][c], dbeta[c] += sum_b part[b][1][c]: every float atomic is a 64-byte transaction at the
+// memory side, and nblk x 2C of them per LayerNorm backward cost more than the LayerNorm itself (1024 x 1536 -> 77 us).
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    // grid (column groups of 64, 16 slices of the partial rows): 16 atomics per parameter instead of nblk
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;      // col over [0, 2C)
+    const int per = (nblk + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float acc = 0.f;
+    if (col < 2 * C)
+        for (int b = b0 + r; b < b1; b += 4) acc += part[(long)b * 2 * C + col];
+    red[r][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (r == 0 && col < 2 * C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(col < C ? dgamma + col : dbeta + (col - C), v);
     }
 }
 
 extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats,
                                   const float* gamma, const float* dres, void* dx, int dx_dtype, float* dgamma,
-                                  float* dbeta, long M, int C, void* dx16, hipStream_t stream) {
+                                  float* dbeta, long M, int C, void* dx16, float* part_ws, hipStream_t stream) {
     UENC_CHECK_ARG(dy && h && stats && gamma && dx && M > 0 && C > 0 && C % 4 == 0 && C <= 6144);
     UENC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     LnBwd p;
@@ -205,9 +241,11 @@ extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, i
     p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32); p.dx16 = (bf16*)dx16;
     p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C;
     long blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    const long cap = (part_ws != nullptr && dgamma != nullptr) ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
+    if (blocks > cap) blocks = cap;
+    p.part = dgamma != nullptr ? part_ws : nullptr;
     const int nv = (C + 255) / 256;
-    const size_t shm = (size_t)2 * C * sizeof(float);
+    const size_t shm = (size_t)(C > 2048 ? 1 : 4) * 2 * C * sizeof(float);      // <= 64 KB
     dim3 grid((unsigned)blocks), block(256);
     if (nv <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, shm, stream, p);
     else if (nv <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, shm, stream, p);
@@ -215,5 +253,7 @@ extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, i
     else if (nv <= 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, shm, stream, p);
     else if (nv <= 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, shm, stream, p);
     else hipLaunchKernelGGL(ln_bwd_kernel<24>, grid, block, shm, stream, p);
+    if (p.part != nullptr)
+        hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((2 * C + 63) / 64, 16), dim3(256), 0, stream, (const float*)p.part, (int)blocks, C, dgamma, dbeta);
     UENC_LAUNCH_RET();
 }

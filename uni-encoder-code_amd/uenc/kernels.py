@@ -126,8 +126,9 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
     if twin is not None and dx_dtype == torch.float32:
         dx16 = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
         twin.append(dx16)
+    part = _scratch("ln_bwd", 2048 * 2 * C * 4, h.device) if dgamma is not None else None
     check(lib.uenc_layernorm_bwd(dy.data_ptr(), dt(dy), h.data_ptr(), dt(h), stats.data_ptr(), gamma.data_ptr(),
-                                 ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, ptr(dx16), stream_ptr()),
+                                 ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, ptr(dx16), ptr(part), stream_ptr()),
           "layernorm_bwd")
     return dx
 
