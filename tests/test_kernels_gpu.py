@@ -311,6 +311,21 @@ def test_gemm_nt_large_tile_path(K, M, N, K_):
     _close(K.gemm_nt(ai, wi, out_dtype=torch.float32), ai.float() @ wi.float().t(), 0, 0)
 
 
+@pytest.mark.parametrize("M,N,K_,split", [(150, 256, 32768, 64), (600, 512, 8192, 16), (1000, 256, 4096 + 64, 16)])
+def test_gemm_nt_splitk_large_tile(K, M, N, K_, split):
+    """Split-K on the 256x256 LDS-DMA kernel (skinny outputs with a long contraction: the mask-embedding gradient)."""
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias = _r(N, seed=3)
+    want = a.float() @ w.float().t() + bias
+    got = K.gemm_nt(a, w, bias=bias, out_dtype=torch.float32, splitk=split)
+    _close(got, want, 2e-3 * float(want.abs().max()), 2e-3)
+    acc = _r(M, N, seed=4)
+    acc0 = acc.clone()
+    K.gemm_nt(a, w, out=acc, splitk=split, accumulate=True)
+    _close(acc, acc0 + want - bias, 2e-3 * float(want.abs().max()), 2e-3)
+
+
 @pytest.mark.parametrize("variant", ["0", "8"])
 @pytest.mark.parametrize("M,N,K_", [(4096, 512, 256), (2048, 576, 192), (8192, 768, 3072), (6400, 264, 200), (2048, 96, 48)])
 def test_gemm_tn_large_tile_path(K, M, N, K_, variant, monkeypatch):

@@ -258,7 +258,9 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
     const int m0 = mt * BM2, n0 = nt * BN2;
-    const int nkt = p.K / BK;
+    // split-K (EPI_NONE, fp32 C, pre-zeroed or accumulated into): blockIdx.y owns k-tiles [kt0, kt0 + nkt), adds its tile atomically
+    const int kt0 = blockIdx.y * (p.klen / BK);
+    const int nkt = min(p.K / BK - kt0, p.klen / BK);
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     for (int q = 0; q < 4; ++q) {
         const int row = q * 64 + (t >> 3), slot = t & 7;
         const int chunk = slot ^ ((row >> 1) & 7);
-        asrc[q] = (const bf16*)p.A + (long)min(m0 + row, p.M - 1) * p.lda + chunk * 8;
-        wsrc[q] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + chunk * 8;
+        asrc[q] = (const bf16*)p.A + (long)min(m0 + row, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
+        wsrc[q] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
     }
     typedef __attribute__((address_space(3))) void lds_void;
     auto issue = [&](int kt, int stage) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     const bool ncol_ok = n < p.N;
     const bool full8 = (n + 8 <= p.N);
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && ncol_ok) {
+    if (p.bias != nullptr && ncol_ok && blockIdx.y == 0) {
         const float4 b0 = *(const float4*)(p.bias + n);
         bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
         if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
@@ -377,8 +379,14 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             }
             if (OUT_F32) {
                 float* c = (float*)p.C + (long)m * p.ldc + n;
-                *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-                if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (EPI == EPI_NONE && p.atomic) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (r < 4 || full8) atomicAdd(c + r, v[r]);
+                } else {
+                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                    if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
             } else {
                 bf16x8 o;
 #pragma unroll
@@ -400,7 +408,8 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n), dim3(T2), 131072, stream, p);
+    const int splits = p.atomic ? (p.K + p.klen - 1) / p.klen : 1;
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n, splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
 }
 
@@ -435,8 +444,11 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
     const bool prof = uenc_prof_on();
     if (prof) uenc_prof_begin(UENC_PROF_GEMM_NT, 2.0 * M * (double)N * K, stream);
     // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
-    const bool big = !p.atomic && a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) &&
-                     ((long)((M + 255) / 256) * ((N + 255) / 256) >= 160) && N >= 256;
+    const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= 256 &&
+                     (p.atomic ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
+                                  !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
+                               : tiles256 >= 160);
     if (big) {
         int rc = UENC_EINVAL;
 #define LAUNCH2(E, F) rc = launch_nt256<E, F>(p, stream)

@@ -9,6 +9,7 @@ Conventions
     on demand), the way a fused gradient-accumulation does: the Functions return None for them.  A
     data-parallel wrapper (`uenc.dp`) can point `.grad` at flat all-reduce buckets beforehand.
 """
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
