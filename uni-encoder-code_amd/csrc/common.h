@@ -47,6 +47,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// v_exp_f32 as is: arguments in the softmax kernels are <= 0 (score minus row maximum / log-sum-exp), results below 2^-126 may flush to zero.
+// The library exp2f wraps the same instruction in a denormal-range rescue (compare, select, scale) -- ~5 extra VALU
+// instructions per call, a third of the softmax arithmetic of these kernels.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // erf-form GELU (torch.nn.GELU default).  erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the
 // bf16 rounding of the stored result): one v_rcp, one v_exp and a 5-term Horner chain instead of libm's erff,
 // which cost more than the GEMM main loop of the fc1 layers when evaluated 128 times per thread in the epilogue.

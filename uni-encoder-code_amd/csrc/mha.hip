@@ -160,13 +160,13 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
                 const float mnew = fmaxf(m_run[i], mloc);
-                const float alpha = exp2f(m_run[i] - mnew);
+                const float alpha = fast_exp2(m_run[i] - mnew);
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = ok[kt][r] ? exp2f(s[kt][r] - mnew) : 0.f;
+                        const float e = ok[kt][r] ? fast_exp2(s[kt][r] - mnew) : 0.f;
                         s[kt][r] = e;
                         sum += e;
                     }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                     const f32x4 dp = mfma16(frag_rows(Vc, kt * 16, fr, fg), dof[i], zero4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pr = ok[kt][r] ? exp2f(s[kt][r] - lse_q[i]) : 0.f;
+                        const float pr = ok[kt][r] ? fast_exp2(s[kt][r] - lse_q[i]) : 0.f;
                         s[kt][r] = pr * (dp[r] - dl_q[i]);
                     }
                 }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void mha_combine_kernel(MhaP p, int nslices) {
     for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.ws_m[(base + s) * MQ + ql]);
     float L = 0.f, O = 0.f;
     for (int s = 0; s < p.nsplit; ++s) {
-        const float w = exp2f(p.ws_m[(base + s) * MQ + ql] - M);
+        const float w = fast_exp2(p.ws_m[(base + s) * MQ + ql] - M);
         L += p.ws_l[(base + s) * MQ + ql] * w;
         O += p.ws_o[((base + s) * MQ + ql) * 32 + d] * w;
     }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
                     const int qi = qt * 16 + 4 * fg + r;
                     bool ok = (key < k_end) && (qi < p.Lq);
                     if (ok && p.mask != nullptr) ok = p.mask[((long)b * p.Lq + qi) * p.mask_rs + key] == 0;
-                    const float pr = ok ? exp2f(sv[r] * sc - lv[r]) : 0.f;
+                    const float pr = ok ? fast_exp2(sv[r] * sc - lv[r]) : 0.f;
                     pt[h2][r] = pr;
                     dst[h2][r] = pr * (dp[r] - dv4[r]);
                 }

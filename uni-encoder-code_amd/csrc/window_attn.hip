@@ -28,8 +28,10 @@
 // Algorithmic HBM bytes per token per head: fwd read 3*64 + write 64; bwd read 5*64 + write 3*64.
 #include "common.h"
 #include "lds_frag.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
+
 
 struct WAttn {
     const bf16* qkv;        // (B, H, W, 3C)
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
     for (int kt = 0; kt < NTILES; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = exp2f(s[kt][r] - mx);
+            const float e = fast_exp2(s[kt][r] - mx);
             s[kt][r] = e;
             sum += e;
         }
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
             for (int kt = 0; kt < NTILES; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[kt][r] - mx);
+                    const float e = fast_exp2(s[kt][r] - mx);
                     s[kt][r] = e;
                     sum += e;
                 }
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
             const float inv = 1.0f / sum;
             if (fg == 0) { lse[qi] = mx + log2f(sum); delta[qi] = dl; }     // log2-domain log-sum-exp
             __builtin_amdgcn_sched_barrier(0);
-            const bool qreal = qi < p.N;
+            const float qreal = qi < p.N ? 1.f : 0.f;
 #pragma unroll
             for (int kt = 0; kt < NTILES; ++kt) {
                 const f32x4 dp = mfma16(frag_rows(Vs, kt * 16, fr, fg), dof, zero4);     // dP^T[key][q] = V[key] . dO[q]
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                 for (int r = 0; r < 4; ++r) {
                     const float ds = s[kt][r] * inv * (dp[r] - dl);
                     s[kt][r] = ds;
-                    if (qreal) dsacc[kt][r] += ds;          // keys >= N have P = 0 exactly
+                    dsacc[kt][r] += ds * qreal;              // (keys >= N have P = 0 exactly; queries >= N are zeroed here)
                 }
                 if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                         for (int r = 0; r < 4; ++r) {
                             float v = sv[r] * sc + bv[r];
                             if (masked && (int)((rq >> (8 * r)) & 0xffu) != ridk) v -= 100.0f * LOG2E;
-                            const float pr = exp2f(v - lv[r]);
+                            const float pr = fast_exp2(v - lv[r]);
                             pt[h2][r] = pr;
                             dst[h2][r] = pr * (dp[r] - dv4[r]);
                         }
