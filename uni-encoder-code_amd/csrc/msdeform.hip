@@ -13,6 +13,7 @@
 // full-rate atomic shape); binned form (below) = records replayed per block of value pixels, see "backward, binned".
 // `value` may be fp32 (the reference's contract) or bf16 (half the gather bytes).
 #include "common.h"
+#include <stdlib.h>
 
 struct MsdaP {
     const void* value; int v_f32;
@@ -202,6 +203,7 @@ struct MsdaBins {
     long roff[MSDA_TL];                                  // first record slot of the level within a (image, head)
     long rtot;                                           // record slots per (image, head)
     int nblk, nwork;                                     // bins / pass-B work items per (image, head)
+    int variant;                                         // timing experiments only (UENC_MSDA_VARIANT), 0 in production
     int* count;                                          // [B * M * nblk] x MSDA_CNT_STRIDE ints (zeroed by the launcher)
     MsdaRec* recs;                                       // [B * M][rtot]
 };
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
         const int s = j8 + round * 8;
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) code[round][tp] = 0u;
-        if (live && s < LP) {
+        if (live && s < LP && bn.variant != 1) {
             const int l = s / p.P;
             const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
             MsdaTap t;
@@ -302,13 +304,14 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
         }
     }
     const bool any_ovf = __ballot(ovfbits != 0u) != 0ull;       // wave-uniform: the shuffles below are skipped when nothing overflowed
-    if (!live) return;
+    if (!live || bn.variant == 2) return;
 
     // ---- gather phase: lane = 4 channels ----
     const int gl0 = (tid & 63) & ~7;           // first lane of this group within the wave
     const long vstride = (long)p.M * D;
     const long vbase = (long)b * p.S * vstride + (long)m * D + c4;
     const float4 top = ldv4(p.grad_out, p.go_f32, grp * D + c4);
+    float keep_w[2] = {0.f, 0.f}, keep_h[2] = {0.f, 0.f}, keep_a[2] = {0.f, 0.f};
     for (int l = 0; l < p.L; ++l) {
         const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
         const long lbase = vbase + p.level_start[l] * vstride;
@@ -350,10 +353,20 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
                 g_h += __shfl_xor(g_h, o);
                 g_a += __shfl_xor(g_a, o);
             }
-            if (j8 == 0) {
-                *(float2*)(p.grad_loc + (grp * LP + s) * 2) = make_float2(g_w, g_h);
-                p.grad_attn[grp * LP + s] = g_a;
+            // every lane of the group now holds the sums: lane (s & 7) keeps sample s, so that the group's L*P results leave as
+            // contiguous 64-byte rows (8 lanes x float2) instead of one 8-byte store per sample from lane 0
+            if (j8 == (s & 7)) {
+                if (s < 8) { keep_w[0] = g_w; keep_h[0] = g_h; keep_a[0] = g_a; }
+                else { keep_w[1] = g_w; keep_h[1] = g_h; keep_a[1] = g_a; }
             }
+        }
+    }
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const int s = j8 + 8 * rnd;
+        if (s < LP) {
+            *(float2*)(p.grad_loc + (grp * LP + s) * 2) = make_float2(keep_w[rnd], keep_h[rnd]);
+            p.grad_attn[grp * LP + s] = keep_a[rnd];
         }
     }
 }
@@ -546,6 +559,7 @@ extern "C" int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int6
     p.grad_value = grad_value; p.grad_loc = grad_loc; p.grad_attn = grad_attn;
     MsdaBins bn;
     if (shapes_host != nullptr && workspace != nullptr && msda_plan_bins(shapes_host, L, Lq, P, D, bn)) {
+        { const char* e = getenv("UENC_MSDA_VARIANT"); bn.variant = e ? atoi(e) : 0; }
         long tot = 0;
         for (int l = 0; l < L; ++l) tot += shapes_host[2 * l] * shapes_host[2 * l + 1];
         const long nbins = (long)B * M * bn.nblk;
