@@ -122,6 +122,10 @@ int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dt
  * (atomic adds), or, for a descriptor with store != 0 and nsplit == 1, overwrites them with plain stores.
  * flops = 2 * sum(M N K), used by uenc_prof_* only. */
 int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, void* stream);
+/* The same for the register-staged kernel (any M, fp32|bf16 operands, 128 x 128 tiles): descriptors of 96 bytes
+ *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin, 0; }
+ * tiles_k = ceil(K / 128), mlen % 64 == 0, item_begin = exclusive prefix sum of ceil(N / 128) * tiles_k * nsplit. */
+int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double flops, void* stream);
 
 /* ---- LayerNorm over the last dimension (C % 4 == 0, C <= 6144) --------------------------------------
  * y = LN(x + res) * gamma + beta; optional h_out <- x + res (fp32); optional stats <- (mean, rstd) per row.

@@ -369,3 +369,34 @@ def test_conv3x3_tokens_fn(ops):
     ref.backward(dy.to(torch.bfloat16).float())
     _check("y", y, ref, 1e-2); _check("dx", x.grad, x2.grad, 2e-2); _check("dw", w.grad, w2.grad, 2e-2)
     ops.CACHE.invalidate()
+
+
+def test_wgrad_queue_small_grouped(ops):
+    """The register-staged grouped kernel: ragged M, fp32 and bf16 operands, several problems in one launch."""
+    from uenc import kernels as K
+    q = ops.WGRADS
+    g = torch.Generator().manual_seed(4)
+    probs = [(300, 256, 256, torch.float32, torch.bfloat16), (300, 2048, 256, torch.bfloat16, torch.bfloat16),
+             (150, 96, 200, torch.float32, torch.float32), (5000, 264, 136, torch.bfloat16, torch.float32)]
+    held = []
+    q.callback_armed = True
+    try:
+        for (M, N, Kd, tdy, tx) in probs:
+            dy = (torch.randn(M, N, generator=g) * 0.5).to(tdy).cuda()
+            x = torch.randn(M, Kd, generator=g).to(tx).cuda()
+            gw0, gb0 = torch.randn(N, Kd, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+            gw, gb = gw0.clone(), gb0.clone()
+            assert q.eligible_small(dy, x, gw) and not q.eligible(dy, x, gw)
+            q.add_small(dy, x, gw, gb)
+            held.append((dy, x, gw0, gb0, gw, gb))
+        assert q.small_items > 0
+    finally:
+        q.callback_armed = False
+        q.flush()
+    assert q.small_items == 0 and not q.small
+    for dy, x, gw0, gb0, gw, gb in held:
+        d16, x16 = dy.to(torch.bfloat16).double(), x.to(torch.bfloat16).double()
+        ref = gw0.double() + d16.t() @ x16
+        assert float((gw.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+        refb = gb0.double() + d16.sum(0)
+        assert float((gb.double() - refb).abs().max()) < 2e-3 * float(refb.abs().max())

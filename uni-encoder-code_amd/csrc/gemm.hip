@@ -524,14 +524,13 @@ __device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[
     }
 }
 
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
+__device__ __forceinline__ void tn_small_body(const GemmTN& p, int tile, int msplit) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
     const int ntile = tile / p.tiles_k, ktile = tile - ntile * p.tiles_k;
     const int n0 = ntile * BN, k0 = ktile * BM;
-    const int mbeg = blockIdx.y * p.mlen;
+    const int mbeg = msplit * p.mlen;
     const int mend = min(p.M, mbeg + p.mlen);
     const int nit = (mend - mbeg + BK - 1) / BK;
 
@@ -645,6 +644,48 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
+    tn_small_body(p, blockIdx.x, blockIdx.y);
+}
+
+// Grouped form of the register-staged kernel (any M, fp32 or bf16 operands): the decoder's ~120 small weight gradients per
+// step are each a 4-workgroup launch that lasts ~20 us of pure latency; queued and launched together they overlap.
+struct TnSmallDesc {
+    const void* dY; const void* X; float* dW; float* db;
+    long ldy, ldx, ldw;
+    int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin, pad_;
+};
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_grouped_small_kernel(const TnSmallDesc* __restrict__ table, int n) {
+    const int item = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].item_begin <= item) lo = mid; else hi = mid - 1;
+    }
+    const TnSmallDesc d = table[lo];
+    GemmTN p;
+    p.dY = d.dY; p.dy_f32 = d.dy_f32; p.ldy = d.ldy; p.X = d.X; p.x_f32 = d.x_f32; p.ldx = d.ldx;
+    p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = 0;
+    const int local = item - d.item_begin;
+    tn_small_body(p, local / d.nsplit, local % d.nsplit);
+}
+
+// table: n descriptors (device memory) of 96 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit,
+// item_begin, 0}: row-major dY [M][N] / X [M][K], fp32 (ld % 4 == 0) or bf16 (ld % 8 == 0), 16-byte aligned, N % 8 == 0,
+// K % 8 == 0; tiles_k = ceil(K / 128); mlen (tokens per split) % 64 == 0; descriptor i owns items
+// [item_begin, item_begin + ceil(N / 128) * tiles_k * nsplit).  dW[n][k] += sum_m dY[m][n] X[m][k]; db[n] += sum_m dY[m][n].
+extern "C" int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double flops, hipStream_t stream) {
+    UENC_CHECK_ARG(table && n > 0 && total_items > 0 && ((uintptr_t)table & 7) == 0);
+    static_assert(sizeof(TnSmallDesc) == 96, "descriptor layout is part of the ABI");
+    const bool prof = uenc_prof_on();
+    if (prof) uenc_prof_begin(UENC_PROF_GEMM_TN, flops, stream);
+    hipLaunchKernelGGL(gemm_tn_grouped_small_kernel, dim3((unsigned)total_items), dim3(GEMM_THREADS), 0, stream, (const TnSmallDesc*)table, n);
+    if (prof) uenc_prof_end(stream);
+    UENC_LAUNCH_RET();
 }
 
 

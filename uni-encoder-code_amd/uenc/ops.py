@@ -190,12 +190,17 @@ class WgradQueue:
     _DESC = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
              ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("tiles_k", "<i4"), ("mlen", "<i4"), ("nsplit", "<i4"),
              ("item_begin", "<i4"), ("store", "<i4")]
+    _DESC_SMALL = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
+                   ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("dy_f32", "<i4"), ("x_f32", "<i4"), ("tiles_k", "<i4"),
+                   ("mlen", "<i4"), ("nsplit", "<i4"), ("item_begin", "<i4"), ("pad", "<i4")]
     FLUSH_ITEMS = {256: 768, 128: 1536}          # ~3 waves of workgroups (1 resp. 2 per CU)
     TOKENS_PER_ITEM = {256: 16384, 128: 65536}   # token range of one work item (256 / 1024 k-steps of 64)
 
     def __init__(self):
         self.pending = {256: [], 128: []}        # tile -> [(desc tuple without item_begin, items, keepalive)]
         self.items = {256: 0, 128: 0}
+        self.small = []                          # descriptors for the register-staged kernel (small / fp32-operand problems)
+        self.small_items = 0
         self.notify = []
         self.callback_armed = False
         self.enabled = True
@@ -207,6 +212,43 @@ class WgradQueue:
                 and dy.stride(1) == 1 and x.stride(1) == 1 and gw.stride(1) == 1
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
                 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and gw.dtype == F32)
+
+    @staticmethod
+    def eligible_small(dy, x, gw) -> bool:
+        def ok(t):
+            return (t.dim() == 2 and t.is_cuda and t.stride(1) == 1 and t.data_ptr() % 16 == 0 and
+                    ((t.dtype == BF16 and t.stride(0) % 8 == 0) or (t.dtype == F32 and t.stride(0) % 4 == 0)))
+        return (ok(dy) and ok(x) and x.shape[0] == dy.shape[0] and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+                and gw.dtype == F32 and gw.stride(1) == 1 and gw.shape == (dy.shape[1], x.shape[1]))
+
+    def add_small(self, dy, x, gw, gb, notify=()):
+        """Queue a problem for the grouped register-staged kernel (launched with the others at flush time)."""
+        M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
+        mt = -(-M // 64)
+        nsplit = max(1, min(mt // 8, -(-M // 2048)))
+        mlen = -(-mt // nsplit) * 64
+        nsplit = -(-M // mlen)
+        tiles_k = -(-Kd // 128)
+        items = -(-N // 128) * tiles_k * nsplit
+        self.small.append(((dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else 0,
+                            dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, int(dy.dtype == F32), int(x.dtype == F32), tiles_k, mlen,
+                            nsplit), items, (dy, x, gw, gb)))
+        self.small_items += items
+        self.notify.extend(p for p in notify if p is not None)
+        self._arm()
+        if not self.callback_armed or self.small_items >= 4096:
+            self.flush()
+
+    def _arm(self):
+        if not self.callback_armed:
+            try:                                  # only valid while the autograd engine is running a backward pass
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self.callback_armed = True
+            except RuntimeError:
+                pass
+
+    def busy(self) -> bool:
+        return bool(self.notify or self.items[256] or self.items[128] or self.small_items)
 
     def add(self, dy, x, gw, gb, notify=()):
         M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
@@ -220,12 +262,7 @@ class WgradQueue:
                                     dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, tiles_k, mlen, nsplit), items, (dy, x, gw, gb)))
         self.items[tile] += items
         self.notify.extend(p for p in notify if p is not None)
-        if not self.callback_armed:
-            try:                                  # only valid while the autograd engine is running a backward pass
-                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
-                self.callback_armed = True
-            except RuntimeError:
-                pass
+        self._arm()
         if not self.callback_armed or self.items[tile] >= self.FLUSH_ITEMS[tile]:
             self.flush()
 
@@ -258,6 +295,20 @@ class WgradQueue:
             self.launch(tile, [d + (items, 0) for d, items, _ in ent], ent[0][2][0].device)
             self.pending[tile] = []
             self.items[tile] = 0
+        if self.small:
+            import numpy as np
+            from .capi import check, lib, stream_ptr
+            desc = np.zeros(len(self.small), dtype=self._DESC_SMALL)
+            begin, flops = 0, 0.0
+            for i, (d, items, _) in enumerate(self.small):
+                desc[i] = d + (begin, 0)
+                begin += items
+                flops += 2.0 * d[7] * d[8] * d[9]
+            dev = self.small[0][2][0].device
+            tab = torch.from_numpy(desc.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
+            check(lib.uenc_gemm_tn_grouped_small(tab.data_ptr(), len(self.small), begin, flops, stream_ptr()), "gemm_tn_grouped_small")
+            self.small = []
+            self.small_items = 0
         if self.notify:
             params, self.notify = self.notify, []
             _notify(*params)
@@ -273,7 +324,7 @@ def flush_wgrads():
 
 def _tn_notify(*params):
     """Gradient-ready notification that keeps its place behind queued wgrad groups."""
-    if WGRADS.notify or WGRADS.items[256] or WGRADS.items[128]:
+    if WGRADS.busy():
         WGRADS.notify.extend(p for p in params if p is not None)
     else:
         _notify(*params)
@@ -284,8 +335,11 @@ def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.
     if WGRADS.enabled and WGRADS.eligible(dy, x, gw):
         WGRADS.add(dy, x, gw, gb, notify)
         return
+    if WGRADS.enabled and WGRADS.eligible_small(dy, x, gw):
+        WGRADS.add_small(dy, x, gw, gb, notify)
+        return
     K.gemm_tn(dy, x, gw, gb)
-    if WGRADS.notify or WGRADS.items[256] or WGRADS.items[128]:
+    if WGRADS.busy():
         WGRADS.notify.extend(p for p in notify if p is not None)     # keep notification order behind the queued groups
     else:
         _notify(*notify)
