@@ -376,7 +376,10 @@ def _twin(t: torch.Tensor) -> Optional[torch.Tensor]:
 def _as_bf16_operand(t2: torch.Tensor) -> torch.Tensor:
     if t2.dtype == F32 and t2.shape[0] >= _BIG_M and t2.is_contiguous() and t2.numel() % 8 == 0:
         tw = _twin(t2)
-        return tw if tw is not None else K.cast_bf16(t2)
+        if tw is None:
+            tw = K.cast_bf16(t2)
+            _register_twin(t2, tw)          # the same activation often feeds several GEMMs (k / v projections of every decoder
+        return tw                           # layer, and the weight-gradient GEMM of each of them in the backward)
     return t2
 
 
