@@ -193,8 +193,10 @@ class WgradQueue:
     _DESC_SMALL = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
                    ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("dy_f32", "<i4"), ("x_f32", "<i4"), ("tiles_k", "<i4"),
                    ("mlen", "<i4"), ("nsplit", "<i4"), ("item_begin", "<i4"), ("pad", "<i4")]
-    FLUSH_ITEMS = {256: 768, 128: 1536}          # ~3 waves of workgroups (1 resp. 2 per CU)
-    TOKENS_PER_ITEM = {256: 16384, 128: 65536}   # token range of one work item (256 / 1024 k-steps of 64)
+    # measured on the Swin-L problem sets (tools/wgrad_group_bench.py): many short items beat few long ones (balance, more loads in
+    # flight) until the per-item atomic burst shows, around 4k-8k tokens
+    FLUSH_ITEMS = {256: 1536, 128: 6144}         # a few waves of workgroups (1 resp. 2 per CU)
+    TOKENS_PER_ITEM = {256: 8192, 128: 4096}     # token range of one work item (128 / 64 k-steps of 64)
 
     def __init__(self):
         self.pending = {256: [], 128: []}        # tile -> [(desc tuple without item_begin, items, keepalive)]
@@ -252,7 +254,9 @@ class WgradQueue:
 
     def add(self, dy, x, gw, gb, notify=()):
         M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
-        tile = 256 if (N % 256 == 0 and Kd % 256 == 0) or (N >= 1024 and Kd >= 1024) else 128
+        # 256 x 256 tiles re-read the operands half as often as 128 x 128 ones; they win unless padding N, K up to 256 wastes too much
+        pad = lambda t: (-(-N // t) * t) * (-(-Kd // t) * t)
+        tile = 256 if pad(256) <= 1.3 * pad(128) else 128
         nsplit = max(1, -(-M // self.TOKENS_PER_ITEM[tile]))
         mlen = -(-(M // 64) // nsplit) * 64
         nsplit = -(-M // mlen)
