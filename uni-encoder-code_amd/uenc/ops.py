@@ -195,7 +195,8 @@ class WgradQueue:
                    ("mlen", "<i4"), ("nsplit", "<i4"), ("item_begin", "<i4"), ("pad", "<i4")]
     # measured on the Swin-L problem sets (tools/wgrad_group_bench.py): many short items beat few long ones (balance, more loads in
     # flight) until the per-item atomic burst shows, around 4k-8k tokens
-    FLUSH_ITEMS = {256: 1536, 128: 6144}         # a few waves of workgroups (1 resp. 2 per CU)
+    FLUSH_ITEMS = {256: 4096, 128: 16384}        # ~16 / 32 waves of workgroups per launch (bigger groups measured a little faster;
+                                                 # flushing only at the end of backward would stall the gradient all-reduce overlap)
     TOKENS_PER_ITEM = {256: 8192, 128: 4096}     # token range of one work item (128 / 64 k-steps of 64)
 
     def __init__(self):
