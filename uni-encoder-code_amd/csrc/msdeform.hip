@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaP p) {
 // slower still (~3 cycles per lane).  The binned form sums on chip without float atomics.  Every level is cut into
 // 4 x 4 blocks of value pixels, one bin of records per (image, head, block):
 //   pass A (msda_bwd_bin_kernel): the gather half of the backward (grad_loc, grad_attn), 8 lanes x 4 channels per
-//     (query, head); instead of adding its 4 taps to grad_value, a sample appends ONE 24-byte record {query, tap pixels,
+//     (query, head); instead of adding its 4 taps to grad_value, a sample appends ONE 24-byte record ({query, tap position} + 4 tap weights,
 //     4 tap weights} to the bin of each block its taps touch (1 - 4).  A workgroup = 32 consecutive queries of one head:
 //     its appends are first counted per bin in an LDS hash table, so a bin's counter sees one returning atomic per
 //     workgroup, not per record (integer atomics are memory-side transactions too: per-record counters cost as much as
@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaP p) {
 #define MSDA_BS 4               // block edge (pixels)
 #define MSDA_CNT_STRIDE 32      // ints between bin counters: one 128-byte line each (counters sharing a line serialise)
 #define MSDA_HASH 256
-struct MsdaRec { int q; unsigned pos; float w[4]; };      // pos: (row + 1) | (column + 1) << 8 of tap (0,0) relative to the block (-1 .. 3);
-                                                          // w[dy*2+dx] = bilinear weight x attention weight of the tap, 0 outside the level
+// A record, stored as two arrays (one 8-byte and one 16-byte load in pass B):
+//   hd = {query, pos}: pos = (row + 1) | (column + 1) << 8 of tap (0,0) relative to the block (-1 .. 3);
+//   w[dy*2+dx] = bilinear weight x attention weight of the tap, 0 outside the level
 struct MsdaBins {
     int nbx[MSDA_TL], boff[MSDA_TL], cap[MSDA_TL];       // blocks per row; first bin of the level; records per bin of the level
     int nsplit[MSDA_TL], woff[MSDA_TL];                  // pass-B slices per bin; first work item of the level
@@ -205,7 +206,8 @@ struct MsdaBins {
     int nblk, nwork;                                     // bins / pass-B work items per (image, head)
     int variant;                                         // timing experiments only (UENC_MSDA_VARIANT), 0 in production
     int* count;                                          // [B * M * nblk] x MSDA_CNT_STRIDE ints (zeroed by the launcher)
-    MsdaRec* recs;                                       // [B * M][rtot]
+    int2* rec_hd;                                        // [B * M][rtot]
+    float4* rec_w;                                       // [B * M][rtot]
 };
 
 __device__ __forceinline__ void atomic_add4(float* g, const float4& v) {
@@ -290,16 +292,16 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
                 if (slot >= bn.cap[l]) { ovfbits |= 1u << (4 * round + tp); continue; }
                 const int cy = t.h0 + (tp >> 1), cx = t.w0 + (tp & 1);
                 const int by0 = cy / MSDA_BS * MSDA_BS, bx0 = cx / MSDA_BS * MSDA_BS;
-                MsdaRec rec;
-                rec.q = q;
-                rec.pos = (unsigned)(t.h0 - by0 + 1) | ((unsigned)(t.w0 - bx0 + 1) << 8);
+                float wk[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int y = t.h0 + (k >> 1), x = t.w0 + (k & 1);
-                    rec.w[k] = (y >= 0 && y < Hl && x >= 0 && x < Wl) ? wt[k] : 0.f;       // taps outside the level carry nothing
+                    wk[k] = (y >= 0 && y < Hl && x >= 0 && x < Wl) ? wt[k] : 0.f;          // taps outside the level carry nothing
                 }
                 const long binl = (long)(cy / MSDA_BS) * bn.nbx[l] + cx / MSDA_BS;
-                bn.recs[(long)bm * bn.rtot + bn.roff[l] + binl * bn.cap[l] + slot] = rec;
+                const long ri = (long)bm * bn.rtot + bn.roff[l] + binl * bn.cap[l] + slot;
+                bn.rec_hd[ri] = make_int2(q, (int)((unsigned)(t.h0 - by0 + 1) | ((unsigned)(t.w0 - bx0 + 1) << 8)));
+                bn.rec_w[ri] = make_float4(wk[0], wk[1], wk[2], wk[3]);
             }
         }
     }
@@ -416,8 +418,10 @@ __global__ __launch_bounds__(256) void msda_bin_reduce_kernel(MsdaP p, MsdaBins 
     const int cnt = (lo + per < n ? lo + per : n) - lo;
     if (cnt <= 0) return;
     const int b = bm / p.M, m = bm - b * p.M;
-    const MsdaRec* recs = bn.recs + (long)bm * bn.rtot + bn.roff[l] + (long)binl * bn.cap[l] + lo;
-    const long gobase = (long)b * p.Lq * p.M * D + (long)m * D + n16;
+    const long rbase = (long)bm * bn.rtot + bn.roff[l] + (long)binl * bn.cap[l] + lo;
+    const int2* rec_hd = bn.rec_hd + rbase;
+    const float4* rec_w = bn.rec_w + rbase;
+    const long gobase = (long)b * p.Lq * p.M * D + (long)m * D + 2 * n16;        // this lane's channel pair (2 n16, 2 n16 + 1)
     const long gostride = (long)p.M * D;
     const int py = n16 >> 2, px = n16 & 3;                 // this lane's pixel (row of the W operand)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -427,27 +431,22 @@ __global__ __launch_bounds__(256) void msda_bin_reduce_kernel(MsdaP p, MsdaBins 
         for (int j = 0; j < 8; ++j) {
             const int idx = i0 + 8 * g + j;
             int2 hd = make_int2(0, 0);
-            float2 wlo = make_float2(0.f, 0.f), whi = make_float2(0.f, 0.f);
-            if (idx < cnt) {
-                const int2* rp = (const int2*)(recs + idx);
-                hd = rp[0];
-                wlo = *(const float2*)(rp + 1);
-                whi = *(const float2*)(rp + 2);
-            }
+            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < cnt) { hd = rec_hd[idx]; w4 = rec_w[idx]; }
             const int dy = py - ((hd.y & 0xff) - 1), dx = px - (((hd.y >> 8) & 0xff) - 1);
-            float wv = dx ? (dy ? whi.y : wlo.y) : (dy ? whi.x : wlo.x);
+            float wv = dx ? (dy ? w4.w : w4.y) : (dy ? w4.z : w4.x);
             if ((unsigned)dy > 1u || (unsigned)dx > 1u) wv = 0.f;
             { const Bf3 ws = split3(wv); wa[0][j] = ws.t[0]; wa[1][j] = ws.t[1]; wa[2][j] = ws.t[2]; }
             const long gi = gobase + (long)hd.x * gostride;
             if (GO_F32) {
-                const float* go = (const float*)p.grad_out;
-                const Bf3 s0 = split3(go[gi]), s1 = split3(go[gi + 16]);
+                const float2 gv = *(const float2*)((const float*)p.grad_out + gi);
+                const Bf3 s0 = split3(gv.x), s1 = split3(gv.y);
 #pragma unroll
                 for (int c = 0; c < NT; ++c) { t0[c][j] = s0.t[c]; t1[c][j] = s1.t[c]; }
             } else {
-                const bf16* go = (const bf16*)p.grad_out;
-                t0[0][j] = go[gi];
-                t1[0][j] = go[gi + 16];
+                const unsigned pr = *(const unsigned*)((const bf16*)p.grad_out + gi);          // two channels in one dword
+                t0[0][j] = bf16_bits(pr << 16);
+                t1[0][j] = bf16_bits(pr & 0xffff0000u);
             }
         }
 #pragma unroll
@@ -459,18 +458,18 @@ __global__ __launch_bounds__(256) void msda_bin_reduce_kernel(MsdaP p, MsdaBins 
                     acc1 = mfma16(wa[a], t1[c], acc1);
                 }
     }
-    // acc: lane holds pixels 4g .. 4g+3 (register index) of channel n16 (acc0) and n16 + 16 (acc1)
+    // acc: lane holds pixels 4g .. 4g+3 (register index) of channel 2 n16 (acc0) and 2 n16 + 1 (acc1)
     const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
     const int by0 = (binl / bn.nbx[l]) * MSDA_BS, bx0 = (binl % bn.nbx[l]) * MSDA_BS;
     const long vstride = (long)p.M * D;
-    const long lbase = (long)b * p.S * vstride + (long)m * D + n16 + p.level_start[l] * vstride;
+    const long lbase = (long)b * p.S * vstride + (long)m * D + 2 * n16 + p.level_start[l] * vstride;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int y = by0 + g, x = bx0 + rr;               // pixel 4g + rr = (row g, column rr)
         if (y < Hl && x < Wl) {
             float* gp = p.grad_value + lbase + ((long)y * Wl + x) * vstride;
             if (acc0[rr] != 0.f) atomicAdd(gp, acc0[rr]);
-            if (acc1[rr] != 0.f) atomicAdd(gp + 16, acc1[rr]);
+            if (acc1[rr] != 0.f) atomicAdd(gp + 1, acc1[rr]);
         }
     }
 }
@@ -539,7 +538,7 @@ extern "C" long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_hos
     MsdaBins bn;
     if (!shapes_host || B <= 0 || M <= 0 || !msda_plan_bins(shapes_host, L, Lq, P, D, bn)) return 0;
     const long nbins = (long)B * M * bn.nblk;
-    return nbins * MSDA_CNT_STRIDE * 4 + (long)B * M * bn.rtot * (long)sizeof(MsdaRec);
+    return nbins * MSDA_CNT_STRIDE * 4 + (long)B * M * bn.rtot * 24;
 }
 
 // Mirrors ms_deform_attn_backward(...): grad_value must be zero-filled by the caller (it is accumulated);
@@ -566,11 +565,12 @@ extern "C" int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int6
         const long cnt_bytes = nbins * MSDA_CNT_STRIDE * 4;
         const long nchunk = (Lq + 31) / 32;
         UENC_CHECK_ARG(tot == S && ((uintptr_t)workspace & 15) == 0 &&
-                       workspace_bytes >= cnt_bytes + (long)B * M * bn.rtot * (long)sizeof(MsdaRec));
+                       workspace_bytes >= cnt_bytes + (long)B * M * bn.rtot * 24);
         const long nitems = (long)B * M * bn.nwork;
         UENC_CHECK_ARG(nbins < (1L << 31) && nchunk * B * M < (1L << 31) && (nitems + 3) / 4 < (1L << 31));
         bn.count = (int*)workspace;
-        bn.recs = (MsdaRec*)((char*)workspace + cnt_bytes);
+        bn.rec_w = (float4*)((char*)workspace + cnt_bytes);                     // 16-byte records first (alignment)
+        bn.rec_hd = (int2*)((char*)workspace + cnt_bytes + (long)B * M * bn.rtot * 16);
         hipError_t e = hipMemsetAsync(bn.count, 0, (size_t)cnt_bytes, stream);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(msda_bwd_bin_kernel, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
