@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaP p) {
 // slower still (~3 cycles per lane).  The binned form sums on chip without float atomics.  Every level is cut into
 // 4 x 4 blocks of value pixels, one bin of records per (image, head, block):
 //   pass A (msda_bwd_bin_kernel): the gather half of the backward (grad_loc, grad_attn), 8 lanes x 4 channels per
-//     (query, head); instead of adding its 4 taps to grad_value, a sample appends ONE 24-byte record ({query, tap position} + 4 tap weights,
-//     4 tap weights} to the bin of each block its taps touch (1 - 4).  A workgroup = 32 consecutive queries of one head:
+//     (query, head); instead of adding its 4 taps to grad_value, a sample appends ONE 24-byte record ({query, tap position} +
+//     4 tap weights) to the bin of each block its taps touch (1 - 4).  A workgroup = 32 consecutive queries of one head:
 //     its appends are first counted per bin in an LDS hash table, so a bin's counter sees one returning atomic per
 //     workgroup, not per record (integer atomics are memory-side transactions too: per-record counters cost as much as
 //     the float atomics saved);
