@@ -445,7 +445,8 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
     if (prof) uenc_prof_begin(UENC_PROF_GEMM_NT, 2.0 * M * (double)N * K, stream);
     // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    const bool big = a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= 256 &&
+    const int nmin = (p.variant & 64) ? 256 : 192;      // a 192-wide output still wins on the 256 tile: A is streamed once, not twice
+    const bool big = a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
                      (p.atomic ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
