@@ -106,6 +106,10 @@ int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, void*
 int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                  int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                  void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, void* stream);
+/* `batch` problems of one shape in one launch (problem b: A + b*bsA, W + b*bsW -> C + b*bsC, element strides, byte
+ * offsets multiples of 16); no bias / epilogue; split-K and accumulate as above. */
+int uenc_gemm_nt_batched(const void* A, int a_dtype, long lda, long bsA, const void* W, long ldw, long bsW, void* C, int c_dtype,
+                         long ldc, long bsC, int batch, int M, int N, int K, float alpha, int splitk, int accumulate, void* stream);
 
 /* weight / bias gradient of the same Linear:  dW[n][k] += sum_m dY[m][n] X[m][k];  db[n] += sum_m dY[m][n]
  * (db may be NULL).  dY, X fp32|bf16 row-major; dW, db fp32, accumulated (atomics).  N % 8 == K % 8 == 0.

@@ -40,6 +40,7 @@ struct GemmNT {
     int atomic;    // fp32 atomicAdd into C (split-K or accumulate)
     int variant;   // debug A/B switch
     float alpha;
+    long bsA, bsW, bsC;   // batched form (gemm_nt_kernel only): element strides between the problems of blockIdx.z
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -66,6 +67,11 @@ __device__ __forceinline__ u32x4 load_row8(const void* base, long ld, int row, i
 template <int EPI, int OUT_F32>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
+    if (blockIdx.z > 0) {                        // batched launch: same shapes, operands / output at fixed strides
+        p.A = (const char*)p.A + (long)blockIdx.z * p.bsA * (p.a_f32 ? 4 : 2);
+        p.W += (long)blockIdx.z * p.bsW;
+        p.C = (char*)p.C + (long)blockIdx.z * p.bsC * (OUT_F32 ? 4 : 2);
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -413,9 +419,10 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
     return UENC_OK;
 }
 
-extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
-                            int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
-                            void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, hipStream_t stream) {
+static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
+                        int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
+                        void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, int batch, long bsA, long bsW,
+                        long bsC, hipStream_t stream) {
     UENC_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0);
     UENC_CHECK_ARG(a_dtype == UENC_F32 || a_dtype == UENC_BF16);
     UENC_CHECK_ARG(c_dtype == UENC_F32 || c_dtype == UENC_BF16);
@@ -440,13 +447,14 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
     splitk = (K + p.klen - 1) / p.klen;
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
     p.alpha = alpha;
-    dim3 grid(p.tiles_m * p.tiles_n, splitk), block(GEMM_THREADS);
+    p.bsA = bsA; p.bsW = bsW; p.bsC = bsC;
+    dim3 grid(p.tiles_m * p.tiles_n, splitk, batch), block(GEMM_THREADS);
     const bool prof = uenc_prof_on();
     if (prof) uenc_prof_begin(UENC_PROF_GEMM_NT, 2.0 * M * (double)N * K, stream);
     // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const int nmin = (p.variant & 64) ? 256 : 192;      // a 192-wide output still wins on the 256 tile: A is streamed once, not twice
-    const bool big = a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
+    const bool big = batch == 1 && a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
                      (p.atomic ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
@@ -491,6 +499,25 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
 #undef LAUNCH
     if (prof) uenc_prof_end(stream);
     UENC_LAUNCH_RET();
+}
+
+extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
+                            int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
+                            void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, hipStream_t stream) {
+    return gemm_nt_impl(A, a_dtype, lda, W, ldw, C, c_dtype, ldc, M, N, K, bias, epilogue, aux, ldaux, aux_out, ldaux_out, alpha, splitk,
+                        accumulate, 1, 0, 0, 0, stream);
+}
+
+// `batch` problems of one shape in one launch: problem b reads A + b * bsA, W + b * bsW and writes C + b * bsC (element
+// strides); no bias / epilogue operands (EPI_NONE), fp32 or bf16 C, split-K allowed.  For skinny per-image GEMMs whose
+// single launch cannot fill the chip (the mask-embedding gradient: 150 x 256 outputs over a 131072-long contraction).
+extern "C" int uenc_gemm_nt_batched(const void* A, int a_dtype, long lda, long bsA, const void* W, long ldw, long bsW, void* C, int c_dtype,
+                                    long ldc, long bsC, int batch, int M, int N, int K, float alpha, int splitk, int accumulate,
+                                    hipStream_t stream) {
+    UENC_CHECK_ARG(batch >= 1 && batch <= 65535);
+    UENC_CHECK_ARG((bsA * (a_dtype == UENC_F32 ? 4 : 2)) % 16 == 0 && (bsW * 2) % 16 == 0 && (bsC * (c_dtype == UENC_F32 ? 4 : 2)) % 16 == 0);
+    return gemm_nt_impl(A, a_dtype, lda, W, ldw, C, c_dtype, ldc, M, N, K, nullptr, EPI_NONE, nullptr, 0, nullptr, 0, alpha, splitk, accumulate,
+                        batch, bsA, bsW, bsC, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

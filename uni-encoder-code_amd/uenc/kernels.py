@@ -75,6 +75,19 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = 
     return out
 
 
+def gemm_nt_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, alpha: float = 1.0, splitk: int = 1, accumulate: bool = False):
+    """out[b] (+)= a[b] @ w[b]^T for b in range(B): a (B, M, K) fp32|bf16, w (B, N, K) bf16, out (B, M, N) fp32|bf16, inner strides 1.
+    One launch; with splitk > 1 / accumulate, out must be fp32 (zeroed by the caller for splitk > 1)."""
+    B, M, K = a.shape
+    _, N, _ = w.shape
+    assert a.is_cuda and w.dtype == torch.bfloat16 and w.shape == (B, N, K) and out.shape == (B, M, N)
+    assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
+    check(lib.uenc_gemm_nt_batched(a.data_ptr(), dt(a), a.stride(1), a.stride(0), w.data_ptr(), w.stride(1), w.stride(0), out.data_ptr(), dt(out),
+                                   out.stride(1), out.stride(0), B, M, N, K, float(alpha), int(splitk), int(accumulate), stream_ptr()),
+          "gemm_nt_batched")
+    return out
+
+
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, splitm: int = 0):
     """dw[n, k] += sum_m dy[m, n] * x[m, k];  db[n] += sum_m dy[m, n].  dy bf16, x fp32|bf16, dw/db fp32 (accumulated)."""
     _mat(dy, "dy"); _mat(x, "x"); _mat(dw, "dw")

@@ -890,8 +890,7 @@ class MaskEinsumFn(torch.autograd.Function):
         group = ctx.group
         d16 = group.park(dout.contiguous(), me)
         dme = torch.zeros((B, Q, C), dtype=F32, device=me.device)
-        for b in range(B):
-            K.gemm_nt(d16[b], mf16_chw[b], out=dme[b], splitk=max(1, min(64, HW // 2048)))
+        K.gemm_nt_batched(d16, mf16_chw, dme, splitk=max(1, min(64, HW // 2048)))      # both images in one launch
         # the hub computes the real gradient; autograd only needs ONE defined (storage-free) placeholder to reach it
         ph = None
         if group.first:
