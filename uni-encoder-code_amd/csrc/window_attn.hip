@@ -237,13 +237,14 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
     constexpr int IMG = NK2 * 64, STAGE = 4 * IMG;
     constexpr int OFF_TOK = 2 * STAGE;                 // int tokoff[2][NK2]
     constexpr int OFF_RID = OFF_TOK + 2 * NK2 * 4;     // u8  rid[2][NK2]
-    constexpr int OFF_LSE = OFF_RID + 2 * NK2;         // float lse[NK2], delta[NK2]
-    constexpr int OFF_DEL = OFF_LSE + NK2 * 4;
+    constexpr int OFF_DEL = (OFF_RID + 2 * NK2 + 15) / 16 * 16;     // float delta[NK2]
     constexpr int OFF_PAD = OFF_DEL + NK2 * 4;         // float padacc[96]
+    constexpr int OFF_P = OFF_PAD + 96 * 4;            // bf16 P[key tile][NK2 query rows][16 keys]: the softmax of phase A, read back
+    constexpr int PSUB = NK2 * 32;                     //   transposed (ds_read_b64_tr_b16) as the P / dS operand tiles of phase B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* lse = (float*)(smem + OFF_LSE);
     float* delta = (float*)(smem + OFF_DEL);
     float* padacc = (float*)(smem + OFF_PAD);          // [3][32] q|k|v bias gradient from padding slots, summed over this WG's windows
+    unsigned char* Pimg = smem + OFF_P;
 
     // block -> (head, g): heads 2i / 2i+1 (the two halves of a 128-byte line of q, k, v, dO) on the same XCD
     int head, g;
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
 #pragma unroll
     for (int kt = 0; kt < NTILES; ++kt) dsacc[kt] = zero4;
     for (int t = threadIdx.x; t < 96; t += NTH) padacc[t] = 0.f;
+    for (int t = threadIdx.x; t < NTILES * PSUB / 16; t += NTH) ((u32x4*)Pimg)[t] = (u32x4){0u, 0u, 0u, 0u};     // rows >= NP are never written
 
     int win = g;
     bf16x8 o_next;                                     // saved forward output row of this lane's query, next window
@@ -312,10 +314,9 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
         const bool more = win + G < p.nWinTotal;
 
-        // bias rows come from L2 in groups of 3 key tiles (phase A) / 2 query tiles (phase B), one group ahead of their use
+        // bias rows come from L2 in groups of 3 key tiles, one group ahead of their use
         // (all NTILES at once would be 36 more live registers than the 168 a 9-wave workgroup can have)
         const float* brow0 = p.bias_q + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
-        const float* bcol0 = p.bias_k + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
         float4 bnext[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
@@ -373,9 +374,6 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                 }
                 __builtin_amdgcn_sched_barrier(0);     // bound the loads hoisted ahead (register pressure)
             }
-            // first two query tiles of the key-major bias for phase B
-            bnext[0] = *(const float4*)bcol0;
-            bnext[1] = *(const float4*)(bcol0 + (1 < NTILES ? 16 : 0));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.f;
@@ -390,18 +388,22 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
-            if (fg == 0) { lse[qi] = mx + log2f(sum); delta[qi] = dl; }     // log2-domain log-sum-exp
+            if (fg == 0) delta[qi] = dl;
             __builtin_amdgcn_sched_barrier(0);
             const float qreal = qi < p.N ? 1.f : 0.f;
 #pragma unroll
             for (int kt = 0; kt < NTILES; ++kt) {
                 const f32x4 dp = mfma16(frag_rows(Vs, kt * 16, fr, fg), dof, zero4);     // dP^T[key][q] = V[key] . dO[q]
+                bf16x4 p4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float ds = s[kt][r] * inv * (dp[r] - dl);
+                    const float pn = s[kt][r] * inv;         // P[q][key]
+                    p4[r] = (bf16)pn;
+                    const float ds = pn * (dp[r] - dl);
                     s[kt][r] = ds;
                     dsacc[kt][r] += ds * qreal;              // (keys >= N have P = 0 exactly; queries >= N are zeroed here)
                 }
+                *(bf16x4*)(Pimg + kt * PSUB + qi * 32 + fg * 8) = p4;       // key tile kt, row q, keys 4 fg .. 4 fg + 3
                 if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
             f32x4 dq[2] = {zero4, zero4};                  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
@@ -432,54 +434,40 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                 }
             }
         }
-        __syncthreads();   // lse / delta complete
+        __syncthreads();   // delta and the P image complete
 
-        // ---------------- phase B: this wave's 16 keys x all queries (query-major S): dK, dV ----------------
+        // ---------------- phase B: this wave's 16 keys x all queries: dK, dV ----------------
+        // P[q][key] comes back from LDS already in MFMA operand order (hardware transposing read), which is also the accumulator
+        // order of dP = dO V^T: dS = P * (dP - delta) needs no score recomputation (no QK^T, bias, mask or exp here)
         {
             const int kt = wave, ki = kt * 16 + fr;
             const int ktok = tokoff[ki];
-            const bf16x8 kfB = frag_rows(Ks, kt * 16, fr, fg);
             const bf16x8 vfB = frag_rows(Vs, kt * 16, fr, fg);
-            const int ridk = rid[ki];
+            const unsigned char* Psub = Pimg + kt * PSUB;
             f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
 #pragma unroll
             for (int qb = 0; qb < NKB; ++qb) {
-                f32x4 pt[2], dst[2];
-                const float4 bcur[2] = {bnext[0], bnext[1]};
-                if (qb + 1 < NKB) {
-                    bnext[0] = *(const float4*)(bcol0 + (2 * qb + 2) * 16);
-                    bnext[1] = *(const float4*)(bcol0 + (2 * qb + 3 < NTILES ? 2 * qb + 3 : 0) * 16);
-                }
+                typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                const int prow = 32 * qb + 4 * fg + (fr >> 2), pcol = (fr & 3) * 8;
+                const bf16x4 plo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Psub + prow * 32 + pcol));
+                const bf16x4 phi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Psub + (prow + 16) * 32 + pcol));
+                bf16x8 pb, db;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pb[r] = plo[r]; pb[4 + r] = phi[r]; }
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int qt = 2 * qb + h2;
                     if (qt < NTILES) {
-                        const f32x4 sv = mfma16(frag_rows(Qs, qt * 16, fr, fg), kfB, zero4);    // S[q = 4fg+r][key = fr]
-                        const f32x4 dp = mfma16(frag_rows(dOs, qt * 16, fr, fg), vfB, zero4);
-                        const float4 bb = bcur[h2];
-                        const float4 l4 = *(const float4*)(lse + qt * 16 + 4 * fg);
+                        const f32x4 dp = mfma16(frag_rows(dOs, qt * 16, fr, fg), vfB, zero4);    // dP[q = 4fg+r][key = fr]
                         const float4 d4 = *(const float4*)(delta + qt * 16 + 4 * fg);
-                        const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, lv[4] = {l4.x, l4.y, l4.z, l4.w};
-                        const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-                        unsigned rq = 0;
-                        if (masked) rq = *(const unsigned*)(rid + qt * 16 + 4 * fg);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = sv[r] * sc + bv[r];
-                            if (masked && (int)((rq >> (8 * r)) & 0xffu) != ridk) v -= 100.0f * LOG2E;
-                            const float pr = fast_exp2(v - lv[r]);
-                            pt[h2][r] = pr;
-                            dst[h2][r] = pr * (dp[r] - dv4[r]);
-                        }
+                        db[4 * h2 + 0] = (bf16)((float)pb[4 * h2 + 0] * (dp[0] - d4.x));
+                        db[4 * h2 + 1] = (bf16)((float)pb[4 * h2 + 1] * (dp[1] - d4.y));
+                        db[4 * h2 + 2] = (bf16)((float)pb[4 * h2 + 2] * (dp[2] - d4.z));
+                        db[4 * h2 + 3] = (bf16)((float)pb[4 * h2 + 3] * (dp[3] - d4.w));
                     } else {
-                        pt[h2] = zero4; dst[h2] = zero4;
-                    }
-                }
-                bf16x8 pb, db;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pb[r] = (bf16)pt[0][r]; pb[4 + r] = (bf16)pt[1][r];
-                    db[r] = (bf16)dst[0][r]; db[4 + r] = (bf16)dst[1][r];
+                        for (int r = 0; r < 4; ++r) db[4 * h2 + r] = (bf16)0.f;
+                    }
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -615,7 +603,7 @@ static int launch_bwd(const WAttn& p, float* dtab, hipStream_t stream) {
     using Cf = WCfg<NT>;
     constexpr int NK2 = Cf::NK2;
     const int G = wattn_bwd_groups(p.nWinTotal, p.nH, NT);
-    constexpr size_t shm = (size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 2 * NK2 * 4 + 96 * 4;
+    constexpr size_t shm = ((size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 15) / 16 * 16 + NK2 * 4 + 96 * 4 + (size_t)NT * NK2 * 32;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
