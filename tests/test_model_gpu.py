@@ -211,3 +211,65 @@ def test_full_model_forward_backward_golden(U):
         if cos < cos_e - 0.015 or abs(nr - 1) > abs(nr_e - 1) + 0.03:
             bad.append((n, cos, cos_e, nr, nr_e))
     assert not bad, bad
+
+
+def test_full_size_swin_l_properties(U):
+    """BASELINE configs[2] at its own size (Swin-L ws 12, 1024 x 2048): size-independent properties of the whole path, and the
+    fp32 oracle's forward on one full-size image (about 15 s of CPU work) with the boolean attention masks pinned to it."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    from oracle import fill, torch_ref as T
+    from uenc.d2 import build_model
+    from uenc import ops
+    model = build_model(bench.make_cfg("cuda"))
+    _fill(model)
+    model.eval()
+    g = torch.Generator().manual_seed(7)
+    imgs = [torch.randint(0, 256, (3, bench.H_IMG, bench.W_IMG), generator=g).float() for _ in range(2)]
+    mk = lambda i, t: {"left_image": imgs[i].cuda(), "task": t, "type": "segmentation", "height": bench.H_IMG, "width": bench.W_IMG}
+    two = [mk(0, "The task is panoptic"), mk(1, "The task is semantic")]
+    pred = model.sem_seg_head.predictor
+    # -- the oracle at full size, one image; its masks drive the product (the discrete path is pinned, see the module docstring)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = fill.state_dict_for(T.model_param_shapes(T.ModelCfg(swin=T.SWIN_L)))
+    with torch.no_grad():
+        oref = T.oneformer_forward([{"left_image": imgs[0], "task": "The task is panoptic"}], sd, T.ModelCfg(swin=T.SWIN_L), upsample=False)
+        pred.forced_attn_masks = [m.cuda() for m in oref["attn_masks"]]
+        one, _ = model.forward_features(two[:1])
+        pred.forced_attn_masks = None
+    r_logits, r_masks = rel(one["pred_logits"], oref["pred_logits"]), rel(one["pred_masks"], oref["pred_masks"])
+    print("full size vs oracle: logits rel", r_logits, "masks rel", r_masks)
+    assert r_logits < 3e-2 and r_masks < 3e-2
+    # -- determinism: the forward has no atomics, two runs are bitwise equal
+    with torch.no_grad():
+        a, _ = model.forward_features(two)
+        b, _ = model.forward_features(two)
+    assert torch.equal(a["pred_masks"], b["pred_masks"]) and torch.equal(a["pred_logits"], b["pred_logits"])
+    # -- batch independence: image 0 alone == image 0 inside a batch of two (per-image statistics, windows and queries only).
+    #    Not bitwise: the batch size changes GEMM tilings / split counts, and free-running thresholded masks amplify that.
+    with torch.no_grad():
+        solo, _ = model.forward_features(two[:1])
+    r = rel(a["pred_masks"][:1], solo["pred_masks"]), rel(a["pred_logits"][:1], solo["pred_logits"])
+    print("batch independence rel", r)
+    assert r[0] < 3e-2 and r[1] < 3e-2
+    # -- backward linearity: the gradients of 2 x loss are 2 x the gradients of the loss (a power of two, so every bf16 rounding
+    #    scales exactly and only the order of float atomics differs; the masks are detached thresholds of the same forward)
+    def grads(scale):
+        for p in model.parameters():
+            p.grad = None
+        ops.CACHE.refresh()
+        out, _ = model.forward_features(two)
+        (scale * bench.synthetic_loss(out)).backward()
+        names = ["backbone.layers.2.blocks.9.mlp.fc1.weight", "backbone.layers.0.blocks.1.attn.relative_position_bias_table",
+                 "sem_seg_head.pixel_decoder.transformer.encoder.layers.3.self_attn.sampling_offsets.weight",
+                 "sem_seg_head.predictor.transformer_cross_attention_layers.4.multihead_attn.in_proj_weight",
+                 "sem_seg_head.pixel_decoder.layer_1.weight", "backbone.patch_embed.proj.weight"]
+        named = dict(model.named_parameters())
+        return {n: named[n].grad.detach().clone() for n in names}
+    g1, g2 = grads(1.0), grads(2.0)
+    for n in g1:
+        assert torch.isfinite(g1[n]).all() and float(g1[n].abs().max()) > 0
+        # (not bitwise: atomics order differs run to run, and a 1-ulp fp32 change upstream can flip a bf16 rounding of a gradient
+        #  operand downstream; cancellation-heavy sums such as the position-table gradient show that as ~1 % noise)
+        assert rel(g2[n], 2.0 * g1[n]) < 3e-2, n
