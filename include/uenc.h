@@ -69,8 +69,9 @@ int uenc_msda_prep_fwd(const float* offaw, long ld, const float* ref, int ref_pe
 /* doffaw (rows, ld) bf16 <- d(loc), d(aw) and the saved softmax aw. */
 int uenc_msda_prep_bwd(const float* dloc, const float* daw, const float* aw, const int64_t* shapes, void* doffaw, long ld,
                        long rows, int Lq, int M, int L, int P, void* stream);
-/* out (nseg, cols) fp32 += column sums of the bf16 matrix x16 over row segments [seg_start[s], seg_start[s+1]) of every
- * image (rows_per_image rows each): per-level sums for the level-embedding gradient. */
+/* out (nseg, 128, cols) fp32 = 128 partial column sums per segment (the caller adds them) of the bf16 matrix x16 over row
+ * segments [seg_start[s], seg_start[s+1]) of every image (rows_per_image rows each): per-level sums for the level-embedding
+ * gradient.  cols % 8 == 0. */
 int uenc_segment_colsum(const void* x16, long ld, int cols, const int64_t* seg_start, int nseg, long rows_per_image, int images,
                         float* out, void* stream);
 

@@ -346,11 +346,12 @@ extern "C" int uenc_msda_prep_bwd(const float* dloc, const float* daw, const flo
     UENC_LAUNCH_RET();
 }
 
-// out[seg][c] += sum over rows [seg_start[seg], seg_start[seg + 1]) of every image of x16[row][c]: the per-level column sums
-// that give the level-embedding gradient (level_embed enters the query through pos, msdeformattn.py:104-113).
+// out[seg][blk][c] = partial sums (blk < 128; the caller adds them) over rows [seg_start[seg], seg_start[seg + 1]) of every image of
+// x16[row][c]: the per-level column sums that give the level-embedding gradient (level_embed enters the query through pos, msdeformattn.py:104-113).
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const bf16* __restrict__ x, long ld, int cols, const int64_t* __restrict__ seg_start,
                                                              int nseg, long rows_per_image, int images, float* __restrict__ out) {
-    // thread = (8-column group cg, row lane r); 16-byte loads; the block's partial goes to `out` by one atomic per column
+    // thread = (8-column group cg, row lane r); 16-byte loads; the block's partial row is STORED (out[seg][block][cols]): hundreds
+    // of workgroups adding into the same few hundred floats would run at the same-address atomic rate (~100 us here)
     __shared__ float red[256][8];
     const int seg = blockIdx.y;
     const long s0 = seg_start[seg], s1 = seg + 1 < nseg ? (long)seg_start[seg + 1] : rows_per_image;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const bf16* __restr
         for (int j = 0; j < 8; ++j) {
             float v = 0.f;
             for (int rr = 0; rr < nr; ++rr) v += red[cg + rr * ncg][j];
-            atomicAdd(out + (long)seg * cols + cg * 8 + j, v);
+            out[((long)seg * gridDim.x + blockIdx.x) * cols + cg * 8 + j] = v;
         }
     }
 }
@@ -382,7 +383,7 @@ extern "C" int uenc_segment_colsum(const void* x16, long ld, int cols, const int
                                    float* out, hipStream_t stream) {
     UENC_CHECK_ARG(x16 && seg_start && out && cols > 0 && nseg > 0 && rows_per_image > 0 && images > 0 && ld >= cols);
     UENC_CHECK_ARG(cols % 8 == 0 && cols <= 2048 && ld % 8 == 0 && ((uintptr_t)x16 & 15) == 0);
-    hipLaunchKernelGGL(segment_colsum_kernel, dim3(256, nseg), dim3(256), 0, stream, (const bf16*)x16, ld, cols, seg_start, nseg,
+    hipLaunchKernelGGL(segment_colsum_kernel, dim3(128, nseg), dim3(256), 0, stream, (const bf16*)x16, ld, cols, seg_start, nseg,
                        rows_per_image, images, out);
     UENC_LAUNCH_RET();
 }

@@ -243,7 +243,9 @@ extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, i
     long blocks = (M + 3) / 4;
     const long cap = (part_ws != nullptr && dgamma != nullptr) ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
     if (blocks > cap) blocks = cap;
-    p.part = dgamma != nullptr ? part_ws : nullptr;
+    // few rows (the decoder's 300-token LayerNorms): the handful of block partials goes straight to dgamma / dbeta by atomics,
+    // a second launch would cost more than it saves
+    p.part = (dgamma != nullptr && blocks * 2 * C > 131072) ? part_ws : nullptr;
     const int nv = (C + 255) / 256;
     const size_t shm = (size_t)(C > 2048 ? 1 : 4) * 2 * C * sizeof(float);      // <= 64 KB
     dim3 grid((unsigned)blocks), block(256);
