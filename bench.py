@@ -14,7 +14,7 @@ The timed region is bracketed by barrier + torch.cuda.synchronize() on both side
 is the MAX over ranks; `value` = images all ranks processed / that time.
 
 `roofline`: the dominant kernel family (bf16 MFMA GEMM) timed per launch with HIP events on its launch
-stream inside the timed region (`uenc_prof_*`), algorithmic FLOPs = 2*M*N*K per launch.
+stream (`uenc_prof_*`) over a repetition of the timed steps, algorithmic FLOPs = 2*M*N*K per launch.
 `cpu_baseline`: the fp32 oracle (oracle/torch_ref.py, a "port") forward+backward on the host cores, on a
 bounded sample (one image at reduced resolution), converted to the metric's unit by pixel count.
 """
@@ -123,8 +123,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
-    ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: capture the step into a HIP graph and replay it (autograd capture is not yet stable on this stack)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,36 +173,19 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     sync()
-    # Launch-bound inner loop (~2000 kernels per step): the whole step is captured once into a HIP graph and replayed.
-    # The graph contains exactly the kernels of the eager step (weight re-casts and gradient zeroing included).
-    graph = None
-    if args.graph and world == 1:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = step()
-            graph.replay()
-            sync()
-        except Exception as e:           # capture not possible: run eagerly and say so
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            sync()
+    # No HIP graph: the step is GPU-bound -- the host enqueues its ~2000 launches in ~50 ms, the GPU needs ~80 (tools/
+    # cpu_bound_probe.py) -- so replaying a captured graph would not shorten it.
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            loss = step()
+        loss = step()
     sync()
     dt = time.perf_counter() - t0
-    # per-launch timing of the dominant kernel family: an eager, event-instrumented pass of the same step
-    # (HIP events recorded inside a captured graph cannot be read back)
+    # per-launch timing of the GEMM families: HIP events recorded on the launch stream around every launch, over a repetition
+    # of the same K steps -- inside the timed region the ~1200 event pairs per step cost 4 % of `value` (measured: 23.4 vs
+    # 24.4 img/s), so the timed region itself stays un-instrumented
     capi.lib.uenc_prof_enable(1)
-    for _ in range(2 if graph is not None else 0):
+    for _ in range(args.steps):
         step()
-    if graph is None:
-        for _ in range(args.steps):
-            step()
     sync()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -240,7 +221,7 @@ def main():
                          "families": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,
                                           "ms_per_step": round(v[0] / max(args.steps, 1), 2), "launches_per_step": v[2] // max(args.steps, 1)}
                                       for k, v in fams.items()}},
-            "loss": round(float(loss), 5), "hip_graph": graph is not None,
+            "loss": round(float(loss), 5),
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
