@@ -193,7 +193,7 @@ def main():
     dt = float(tmax)
 
     fams = {}
-    for kind, name in ((0, "gemm_nt_kernel"), (1, "gemm_tn_kernel")):
+    for kind, name in ((4, "gemm_nt256_kernel"), (0, "gemm_nt_kernel"), (1, "gemm_tn*_kernel")):
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
         capi.lib.uenc_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         fams[name] = (ms.value, fl.value, n.value)

@@ -450,7 +450,6 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     p.bsA = bsA; p.bsW = bsW; p.bsC = bsC;
     dim3 grid(p.tiles_m * p.tiles_n, splitk, batch), block(GEMM_THREADS);
     const bool prof = uenc_prof_on();
-    if (prof) uenc_prof_begin(UENC_PROF_GEMM_NT, 2.0 * M * (double)N * K, stream);
     // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const int nmin = (p.variant & 64) ? 256 : 192;      // a 192-wide output still wins on the 256 tile: A is streamed once, not twice
@@ -458,6 +457,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
                      (p.atomic ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
+    if (prof) uenc_prof_begin(big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream);
     if (big) {
         int rc = UENC_EINVAL;
 #define LAUNCH2(E, F) rc = launch_nt256<E, F>(p, stream)
