@@ -192,11 +192,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
-    fams = {}
+    fams, alg_bytes = {}, {}
     for kind, name in ((4, "gemm_nt256_kernel"), (0, "gemm_nt_kernel"), (1, "gemm_tn*_kernel")):
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        ms, fl, n, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
         capi.lib.uenc_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        capi.lib.uenc_prof_collect_bytes(kind, ctypes.byref(by))
         fams[name] = (ms.value, fl.value, n.value)
+        alg_bytes[name] = by.value
     capi.lib.uenc_prof_enable(0)
 
     if rank == 0:
@@ -205,6 +207,14 @@ def main():
         ms, fl, n = fams[dom]
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         gemm_ms = sum(v[0] for v in fams.values())
+        # L2 <-> fabric bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the committed
+        # summary of the two rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py) is quoted when present
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["families"][dom]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         rec = {
             "metric": "img/s fwd+bwd Swin-L 1024x2048 bs=2 per GPU", "value": round(imgs / dt, 4), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -215,7 +225,8 @@ def main():
                        "model_tflop_per_step_per_gpu": round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3, 2)},
             "model_tflops_per_gpu": round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3 / (dt / args.steps), 1),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": None, "launches_per_step": n // max(args.steps, 1),
+                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, profiles/r01_pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": round(alg_bytes[dom] / max(n, 1)), "launches_per_step": n // max(args.steps, 1),
                          "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3),
                          "families": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,

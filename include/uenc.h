@@ -207,6 +207,8 @@ int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, 
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */
 int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile), 1 gemm_tn*, 4 gemm_nt256 */, double* ms_total, double* flops_total, long* launches);
+/* algorithmic bytes (operands read once + results written once) of the recorded launches of `kind` (gemm_nt kinds). */
+int uenc_prof_collect_bytes(int kind, double* bytes_total);
 
 #ifdef __cplusplus
 }

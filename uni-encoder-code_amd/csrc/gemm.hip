@@ -457,7 +457,15 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
                      (p.atomic ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
-    if (prof) uenc_prof_begin(big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream);
+    if (prof) {
+        // algorithmic HBM bytes: A, W and the output once, plus what the epilogue reads (residual / saved activation) or writes besides
+        const double mn = (double)M * N;
+        double bytes = (double)M * K * (a_dtype == UENC_F32 ? 4 : 2) + (double)N * K * 2 + mn * (c_dtype == UENC_F32 ? 4 : 2);
+        if (epilogue == EPI_RESIDUAL) bytes += mn * 4;
+        if (epilogue == EPI_MUL_DGELU || epilogue == EPI_MUL_DRELU) bytes += mn * 2;
+        if (aux_out != nullptr) bytes += mn * 2;
+        uenc_prof_begin(big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream, batch * bytes);
+    }
     if (big) {
         int rc = UENC_EINVAL;
 #define LAUNCH2(E, F) rc = launch_nt256<E, F>(p, stream)

@@ -8,7 +8,7 @@
 #include "prof.h"
 
 namespace {
-struct Rec { int kind; double flops; hipEvent_t e0, e1; };
+struct Rec { int kind; double flops, bytes; hipEvent_t e0, e1; };
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -26,8 +26,8 @@ hipEvent_t get_event() {
 
 bool uenc_prof_on() { return g_on; }
 
-void uenc_prof_begin(int kind, double flops, hipStream_t stream) {
-    Rec r{kind, flops, get_event(), get_event()};
+void uenc_prof_begin(int kind, double flops, hipStream_t stream, double bytes) {
+    Rec r{kind, flops, bytes, get_event(), get_event()};
     if (r.e0 == nullptr || r.e1 == nullptr) return;
     (void)hipEventRecord(r.e0, stream);
     g_recs.push_back(r);
@@ -57,5 +57,14 @@ extern "C" int uenc_prof_collect(int kind, double* ms_total, double* flops_total
     if (ms_total) *ms_total = ms;
     if (flops_total) *flops_total = fl;
     if (launches) *launches = n;
+    return 0;
+}
+
+// Algorithmic bytes (operands read once + results written once) summed over the recorded launches of `kind`.
+extern "C" int uenc_prof_collect_bytes(int kind, double* bytes_total) {
+    double b = 0.0;
+    for (const Rec& r : g_recs)
+        if (r.kind == kind) b += r.bytes;
+    if (bytes_total) *bytes_total = b;
     return 0;
 }
