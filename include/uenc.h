@@ -107,6 +107,14 @@ int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, void*
 int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                  int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                  void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, void* stream);
+/* Split-K with STORED partial sums (no atomics): split s of `splitk` writes its fp32 partial product to P + s * part_stride
+ * (row stride ldp); the caller sums the slices.  splitk must equal uenc_gemm_nt_splits(K, requested) (the number of non-empty
+ * k-ranges after rounding to 64).  Replaces the reference's torch.einsum("bqc,bchw->bqhw") backward w.r.t. the mask embedding
+ * (model/modeling/transformer_decoder/oneformer_transformer_decoder.py:500) for all prediction heads at once. */
+int uenc_gemm_nt_splits(int K, int splitk);
+int uenc_gemm_nt_partials(const void* A, int a_dtype, long lda, const void* W, long ldw, float* P, long ldp, long part_stride,
+                          int M, int N, int K, float alpha, int splitk, void* stream);
+
 /* `batch` problems of one shape in one launch (problem b: A + b*bsA, W + b*bsW -> C + b*bsC, element strides, byte
  * offsets multiples of 16); no bias / epilogue; split-K and accumulate as above. */
 int uenc_gemm_nt_batched(const void* A, int a_dtype, long lda, long bsA, const void* W, long ldw, long bsW, void* C, int c_dtype,

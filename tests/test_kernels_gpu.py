@@ -400,3 +400,14 @@ def test_msda_prep_kernels(K, L, P):
     want = torch.stack([got.float().view(B, Lq, ld)[:, int(start[s]):(int(start[s + 1]) if s + 1 < len(start) else Lq)].sum((0, 1))
                         for s in range(len(start))])
     _close(sums, want, 1e-3 * float(want.abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("M,N,Kd,split", [(512, 256, 8192, 32), (150, 256, 4096, 7), (1536, 256, 16384, 43), (300, 64, 1024, 5)])
+def test_gemm_nt_splitk_stored_partials(K, M, N, Kd, split):
+    """Split-K with stored partial tiles (both tile classes) against the fp32 product of the same bf16 operands; rows at a
+    non-power-of-two stride like the stacked gradient matrix of ops.MaskHeadsFn."""
+    a = _r(M, Kd + 64, seed=1, scale=0.5, dtype=torch.bfloat16)[:, :Kd]
+    w = _r(N, Kd + 64, seed=2, scale=0.5, dtype=torch.bfloat16)[:, :Kd]
+    got = K.gemm_nt_splitk(a, w, split)
+    want = a.float() @ w.float().t()
+    assert float((got - want).norm() / want.norm()) < 1e-3       # fp32 accumulation of exact bf16 products: order only

@@ -40,6 +40,8 @@ struct GemmNT {
     int atomic;    // fp32 atomicAdd into C (split-K or accumulate)
     int variant;   // debug A/B switch
     float alpha;
+    long part_stride;     // > 0: split-K with STORED partials: split y writes its tile to C + y * part_stride (fp32 elements), no atomics
+    int splits;           // gridDim.y
     long bsA, bsW, bsC;   // batched form (gemm_nt_kernel only): element strides between the problems of blockIdx.z
 };
 
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
         p.W += (long)blockIdx.z * p.bsW;
         p.C = (char*)p.C + (long)blockIdx.z * p.bsC * (OUT_F32 ? 4 : 2);
     }
+    if (OUT_F32 && p.part_stride > 0) p.C = (float*)p.C + (long)blockIdx.y * p.part_stride;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -265,8 +268,10 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
     const int m0 = mt * BM2, n0 = nt * BN2;
     // split-K (EPI_NONE, fp32 C, pre-zeroed or accumulated into): blockIdx.y owns k-tiles [kt0, kt0 + nkt), adds its tile atomically
+    // (or, with part_stride > 0, stores it as partial sum number blockIdx.y: summed by the caller)
     const int kt0 = blockIdx.y * (p.klen / BK);
     const int nkt = min(p.K / BK - kt0, p.klen / BK);
+    if (OUT_F32 && p.part_stride > 0) p.C = (float*)p.C + (long)blockIdx.y * p.part_stride;
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -414,15 +419,14 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int splits = p.atomic ? (p.K + p.klen - 1) / p.klen : 1;
-    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n, splits), dim3(T2), 131072, stream, p);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
 }
 
 static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                         int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                         void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, int batch, long bsA, long bsW,
-                        long bsC, hipStream_t stream) {
+                        long bsC, hipStream_t stream, long part_stride = 0) {
     UENC_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0);
     UENC_CHECK_ARG(a_dtype == UENC_F32 || a_dtype == UENC_BF16);
     UENC_CHECK_ARG(c_dtype == UENC_F32 || c_dtype == UENC_BF16);
@@ -446,6 +450,12 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     p.klen = ((kt + splitk - 1) / splitk) * BK;
     splitk = (K + p.klen - 1) / p.klen;
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
+    p.part_stride = 0; p.splits = splitk;
+    const bool partials = part_stride > 0;
+    if (partials) {       // stored partial sums: plain epilogue per split, no atomics
+        UENC_CHECK_ARG(c_dtype == UENC_F32 && epilogue == EPI_NONE && !accumulate && bias == nullptr && batch == 1 && part_stride % 4 == 0);
+        p.atomic = 0; p.part_stride = part_stride;
+    }
     p.alpha = alpha;
     p.bsA = bsA; p.bsW = bsW; p.bsC = bsC;
     dim3 grid(p.tiles_m * p.tiles_n, splitk, batch), block(GEMM_THREADS);
@@ -454,7 +464,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const int nmin = (p.variant & 64) ? 256 : 192;      // a 192-wide output still wins on the 256 tile: A is streamed once, not twice
     const bool big = batch == 1 && a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
-                     (p.atomic ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
+                     ((p.atomic || partials) ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
     if (prof) {
@@ -514,6 +524,25 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
                             void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, hipStream_t stream) {
     return gemm_nt_impl(A, a_dtype, lda, W, ldw, C, c_dtype, ldc, M, N, K, bias, epilogue, aux, ldaux, aux_out, ldaux_out, alpha, splitk,
                         accumulate, 1, 0, 0, 0, stream);
+}
+
+// Split-K with stored partial sums: split s (of `splitk`) writes sum over its k-range to P + s * part_stride (fp32, ldp); the
+// caller sums the `splitk` slices.  For long contractions with few output tiles (d(mask embeddings): 1536 x 256 outputs over
+// 131072 pixels): fp32 atomics are per-lane 64-byte memory-side transactions, ~10 us per split here; stored tiles are ~1.
+// `splitk` must be a fixed point of the k-range rounding (uenc_gemm_nt_splits gives it), so that every slice is written.
+extern "C" int uenc_gemm_nt_splits(int K, int splitk) {
+    const int kt = (K + BK - 1) / BK;
+    if (splitk < 1) splitk = 1;
+    if (splitk > kt) splitk = kt;
+    const int klen = (kt + splitk - 1) / splitk;
+    return (kt + klen - 1) / klen;
+}
+
+extern "C" int uenc_gemm_nt_partials(const void* A, int a_dtype, long lda, const void* W, long ldw, float* P, long ldp, long part_stride,
+                                     int M, int N, int K, float alpha, int splitk, hipStream_t stream) {
+    UENC_CHECK_ARG(splitk >= 1 && uenc_gemm_nt_splits(K, splitk) == splitk && part_stride >= (long)(M - 1) * ldp + N);
+    return gemm_nt_impl(A, a_dtype, lda, W, ldw, P, UENC_F32, ldp, M, N, K, nullptr, EPI_NONE, nullptr, 0, nullptr, 0, alpha, splitk, 0, 1, 0, 0,
+                        0, stream, part_stride);
 }
 
 // `batch` problems of one shape in one launch: problem b reads A + b * bsA, W + b * bsW and writes C + b * bsC (element

@@ -75,6 +75,21 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = 
     return out
 
 
+def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, splitk: int, *, alpha: float = 1.0) -> torch.Tensor:
+    """sum_k a[m, k] * w[n, k] in fp32 for a long contraction with few output tiles: `splitk` k-ranges computed by separate
+    workgroups, each STORING its partial tile (no atomics), then summed.  a, w bf16 with unit inner stride."""
+    _mat(a, "a"); _mat(w, "w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2 or w.dtype != torch.bfloat16:
+        raise capi.UencError(f"gemm_nt_splitk: a {tuple(a.shape)} vs w {tuple(w.shape)} / {w.dtype}")
+    s = lib.uenc_gemm_nt_splits(K, int(splitk))
+    part = torch.empty((s, M, N), dtype=torch.float32, device=a.device)
+    check(lib.uenc_gemm_nt_partials(a.data_ptr(), dt(a), a.stride(0), w.data_ptr(), w.stride(0), part.data_ptr(), N, M * N, M, N, K,
+                                    float(alpha), s, stream_ptr()), "gemm_nt_partials")
+    return part[0] if s == 1 else part.sum(0)
+
+
 def gemm_nt_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, alpha: float = 1.0, splitk: int = 1, accumulate: bool = False):
     """out[b] (+)= a[b] @ w[b]^T for b in range(B): a (B, M, K) fp32|bf16, w (B, N, K) bf16, out (B, M, N) fp32|bf16, inner strides 1.
     One launch; with splitk > 1 / accumulate, out must be fp32 (zeroed by the caller for splitk > 1)."""

@@ -285,9 +285,9 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
 
         mf16 = mf32.detach().to(torch.bfloat16)
         mf16_chw = mf16.transpose(1, 2).contiguous()
-        mf32, mf_group = ops.mask_feature_hub(mf32)          # the hub sums the ten heads' mask-feature gradients in one GEMM
+        mes = []                                             # mask embeddings of all heads: their einsums share one autograd node
         predictions_class, predictions_mask = [], []
-        cls, msk, attn_mask = self.forward_prediction_heads(output, (mf32, mf16, mf16_chw, H4, W4, mf_group), size_list[0])
+        cls, msk, attn_mask = self.forward_prediction_heads(output, (mf16, H4, W4, mes), size_list[0])
         predictions_class.append(cls); predictions_mask.append(msk)
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
@@ -298,21 +298,24 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
                                                                 key_in=kin[lvl])
             output = self.transformer_self_attention_layers[i](output, query_pos=qe)
             output = self.transformer_ffn_layers[i](output)
-            cls, msk, attn_mask = self.forward_prediction_heads(output, (mf32, mf16, mf16_chw, H4, W4, mf_group),
+            cls, msk, attn_mask = self.forward_prediction_heads(output, (mf16, H4, W4, mes),
                                                                 size_list[(i + 1) % self.num_feature_levels])
             predictions_class.append(cls); predictions_mask.append(msk)
         assert len(predictions_class) == self.num_layers + 1
+        # the eager mask logits become differentiable here: one node for all heads (ops.MaskHeadsFn)
+        predictions_mask = [m.view(B, -1, H4, W4) for m in ops.mask_heads(mf32, mf16_chw, [m.view(B, -1, H4 * W4) for m in predictions_mask], mes)]
         return {"contrastive_logits": output if self.is_train else None,
                 "pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1],
                 "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(predictions_class[:-1], predictions_mask[:-1])]}
 
     def forward_prediction_heads(self, output, mf, attn_mask_target_size):
-        mf32, mf16, mf16_chw, H4, W4, mf_group = mf
+        mf16, H4, W4, mes = mf
         d = _ln(self.decoder_norm, output)
         outputs_class = ops.linear(d, self.class_embed.weight, self.class_embed.bias, out_dtype=torch.float32)
-        me = self.mask_embed(d, out_dtype=torch.bfloat16)
+        me = self.mask_embed(d, out_dtype=torch.bfloat16).contiguous()
         B, Q, _ = me.shape
-        outputs_mask = ops.mask_einsum(me.contiguous(), mf32, mf16, mf16_chw, mf_group).view(B, Q, H4, W4)
+        mes.append(me)
+        outputs_mask = ops.mask_logits_eager(me, mf16).view(B, Q, H4, W4)        # detached: made differentiable at the end of forward
         # (B, Q, S) True = blocked, shared by all heads: resize + sigmoid < 0.5 + the all-blocked-row fix of :454 in one kernel
         am = K.attn_mask(outputs_mask.detach(), attn_mask_target_size)
         return outputs_class, outputs_mask, am

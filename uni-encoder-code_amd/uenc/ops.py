@@ -801,112 +801,76 @@ class MSDeformAttnFunction(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # mask einsum  "bqc,bchw->bqhw"  as batched NT GEMMs against channels-last mask features
 # --------------------------------------------------------------------------------------------
-class MaskFeatGrads:
-    """Collects, over the prediction heads of one decoder forward, what the gradient of the mask features needs.
-
-    Every head contributes dmf[b] += dout_h[b]^T me_h[b] (HW x C from Q = 150 rows): done per head, that is 2 x heads
-    launches that each push the whole 134 MB fp32 map through float atomics (or a read-modify-write) plus the autograd
-    engine's own accumulation.  Instead the heads only park their operands (bf16 rows of one stacked [heads*Q][HW] matrix per
-    image) and `MaskFeatHub.backward`, which autograd runs after all of them, computes the sum as ONE token-contraction
-    GEMM per image, stored once."""
-
-    def __init__(self, n_heads_hint: int = 10):
-        self.n_fwd = 0
-        self.rows = 0
-        self.dout = None        # (B, Mp, HW) bf16
-        self.me = None          # (B, Mp, C) bf16
-        self.first = True
-
-    def park(self, dout, me):
-        B, Q, HW = dout.shape
-        C = me.shape[-1]
-        if self.dout is None:
-            Mp = -(-(self.n_fwd * Q) // 64) * 64
-            self.dout = torch.empty((B, Mp, HW), dtype=BF16, device=dout.device)
-            self.me = torch.zeros((B, Mp, C), dtype=BF16, device=dout.device)       # rows never parked stay zero ...
-        r = self.rows
-        for b in range(B):
-            K.cast_bf16(dout[b], out=self.dout[b, r:r + Q])
-        self.me[:, r:r + Q] = me
-        self.rows = r + Q
-        return self.dout[:, r:r + Q]
-
-    def finish(self):
-        if self.dout is None:
-            return None
-        B, Mp, HW = self.dout.shape
-        C = self.me.shape[-1]
-        if self.rows < Mp:
-            self.dout[:, self.rows:].zero_()                                        # ... and so do theirs (0 x garbage could be NaN)
-        dmf = torch.empty((B, HW, C), dtype=F32, device=self.dout.device)
-        tile = 256 if C % 256 == 0 else 128
-        tiles_k = -(-C // tile)
-        items = -(-HW // tile) * tiles_k
-        descs = [(self.dout[b].data_ptr(), self.me[b].data_ptr(), dmf[b].data_ptr(), 0, HW, C, C, Mp, HW, C, tiles_k, Mp, 1, items, 1)
-                 for b in range(B)]
-        WgradQueue.launch(tile, descs, dmf.device)
-        self.dout = self.me = None
-        return dmf
+def mask_logits_eager(me, mf16_tok):
+    """me (B, Q, C) bf16 x mask features (B, HW, C) bf16 -> (B, Q, HW) fp32 mask logits, outside autograd (see MaskHeadsFn)."""
+    B, Q, C = me.shape
+    HW = mf16_tok.shape[1]
+    assert HW % 8 == 0 and C % 8 == 0
+    out = torch.empty((B, Q, HW), dtype=F32, device=me.device)
+    med = me.detach()
+    for b in range(B):
+        K.gemm_nt(med[b], mf16_tok[b], out=out[b])
+    return out
 
 
-class MaskFeatHub(torch.autograd.Function):
-    """Identity on the mask features in front of the prediction heads; its backward produces their summed gradient."""
+class MaskHeadsFn(torch.autograd.Function):
+    """All prediction heads' mask einsums "bqc,bchw->bqhw" as ONE autograd node.
+
+    The decoder needs every head's mask logits during its forward (they become the next layer's attention mask, a detached
+    threshold), so they are computed eagerly (`mask_logits_eager`) and this node only adopts them as its outputs.  What it buys
+    is the backward: the loss gradients of all heads are available together, so
+      * d(mask embeddings) of all heads is one 1536 x 256 x HW GEMM per image (stacked bf16 gradient rows x mask features)
+        instead of a 150-row, 64-way split-K GEMM per head and image,
+      * d(mask features) is one token-contraction GEMM per image, stored once (no atomics, no accumulation passes over the
+        134 MB map per head).
+    """
 
     @staticmethod
-    def forward(ctx, mf32_tok, group):
-        ctx.group = group
-        return mf32_tok.view_as(mf32_tok)
+    def forward(ctx, mf32_tok, mf16_chw, pre, *mes):
+        ctx.save_for_backward(mf16_chw, *mes)
+        ctx.shape = tuple(mf32_tok.shape)
+        return tuple(pre)
 
     @staticmethod
-    def backward(ctx, g):
-        return ctx.group.finish(), None
+    def backward(ctx, *douts):
+        mf16_chw, *mes = ctx.saved_tensors
+        B, HW, C = ctx.shape
+        n, Q = len(mes), mes[0].shape[1]
+        Mp = -(-(n * Q) // 64) * 64
+        dev = mf16_chw.device
+        D = torch.empty((B, Mp, HW), dtype=BF16, device=dev)          # stacked gradient rows of all heads
+        ME = torch.zeros((B, Mp, C), dtype=BF16, device=dev)
+        for h, (d, me) in enumerate(zip(douts, mes)):
+            r = h * Q
+            if d is None:
+                D[:, r:r + Q].zero_()
+                continue
+            d = d if d.is_contiguous() else d.contiguous()
+            for b in range(B):
+                K.cast_bf16(d[b], out=D[b, r:r + Q])
+            ME[:, r:r + Q] = me
+        if n * Q < Mp:
+            D[:, n * Q:].zero_()                                      # (0 x garbage could be NaN)
+        # d(mask embeddings): rows = heads x queries, contraction over the HW pixels
+        # (split over the pixels so that every CU has a tile; partial tiles are stored and summed, not added atomically)
+        tiles = -(-Mp // 256) * -(-C // 256)
+        split = max(1, min(HW // 512, -(-256 // tiles)))
+        dme = [K.gemm_nt_splitk(D[b], mf16_chw[b], split) for b in range(B)]
+        # d(mask features): contraction over the stacked rows, one stored GEMM per image
+        dmf = None
+        if ctx.needs_input_grad[0]:
+            dmf = torch.empty((B, HW, C), dtype=F32, device=dev)
+            tile = 256 if C % 256 == 0 else 128
+            tiles_k = -(-C // tile)
+            items = -(-HW // tile) * tiles_k
+            WgradQueue.launch(tile, [(D[b].data_ptr(), ME[b].data_ptr(), dmf[b].data_ptr(), 0, D.stride(1), C, C, Mp, HW, C, tiles_k, Mp, 1, items, 1)
+                                     for b in range(B)], dev)
+        return (dmf, None, None) + tuple(torch.stack([dme[b][h * Q:(h + 1) * Q] for b in range(B)]).to(mes[h].dtype) for h in range(n))
 
 
-class MaskEinsumFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, me, mf32_tok, mf16_tok, mf16_chw, group):
-        """me (B, Q, C) bf16 x mask features -> (B, Q, HW) fp32.
-
-        mf32_tok (B, HW, C) fp32 is the differentiable input (the output of `MaskFeatHub`, which owns its gradient: see
-        `MaskFeatGrads`); mf16_tok (B, HW, C) / mf16_chw (B, C, HW) are its detached bf16 operand copies.
-        """
-        B, Q, C = me.shape
-        HW = mf16_tok.shape[1]
-        assert HW % 8 == 0 and C % 8 == 0
-        out = torch.empty((B, Q, HW), dtype=F32, device=me.device)
-        for b in range(B):
-            K.gemm_nt(me[b], mf16_tok[b], out=out[b])
-        ctx.save_for_backward(me, mf16_chw)
-        ctx.HW = HW
-        ctx.group = group
-        group.n_fwd += 1
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        me, mf16_chw = ctx.saved_tensors
-        B, Q, C = me.shape
-        HW = ctx.HW
-        group = ctx.group
-        d16 = group.park(dout.contiguous(), me)
-        dme = torch.zeros((B, Q, C), dtype=F32, device=me.device)
-        K.gemm_nt_batched(d16, mf16_chw, dme, splitk=max(1, min(64, HW // 2048)))      # both images in one launch
-        # the hub computes the real gradient; autograd only needs ONE defined (storage-free) placeholder to reach it
-        ph = None
-        if group.first:
-            group.first = False
-            ph = torch.zeros((1, 1, 1), dtype=F32, device=me.device).expand(B, HW, C)
-        return dme.to(me.dtype), ph, None, None, None
-
-
-def mask_feature_hub(mf32_tok):
-    """-> (mf32 alias to feed `mask_einsum`, group).  One per decoder forward."""
-    group = MaskFeatGrads()
-    return MaskFeatHub.apply(mf32_tok, group), group
-
-
-def mask_einsum(me, mf32_tok, mf16_tok, mf16_chw, group):
-    return MaskEinsumFn.apply(me, mf32_tok, mf16_tok, mf16_chw, group)
+def mask_heads(mf32_tok, mf16_chw, pre, mes):
+    """pre: the eager mask logits per head (list of (B, Q, HW) fp32); mes: the heads' mask embeddings (B, Q, C) bf16."""
+    return MaskHeadsFn.apply(mf32_tok, mf16_chw, list(pre), *mes)
 
 
 # --------------------------------------------------------------------------------------------
