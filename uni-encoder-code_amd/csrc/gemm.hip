@@ -249,17 +249,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
 // Large-tile variant for the GEMMs that carry most of the FLOPs (stage 3 / 4 of the backbone,
 // K % 64 == 0, bf16 A): 256 x 256 x 64 tile, 8 waves (2 x 4), each wave 128(m) x 64(n) = 8 x 4
 // MFMA tiles (128 accumulator VGPRs), one workgroup per CU.  Operands go global -> LDS directly
-// (global_load_lds_dwordx4: no staging registers, 8 instructions per thread per k-tile), two 64 KB
-// stages: the DMA of k-tile t+1 is issued before the 64 MFMAs per wave of k-tile t and waited for
-// after them, one barrier per k-tile.  LDS-DMA writes lane-linearly (wave base + lane * 16 B), so
-// the XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied to the
-// per-lane SOURCE address (cdna_hip_programming.md rule 21).
+// (global_load_lds_dwordx4: no staging registers).  LDS-DMA writes lane-linearly (wave base +
+// lane * 16 B), so the XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is
+// applied to the per-lane SOURCE address (cdna_hip_programming.md rule 21).
+// Main loop PIPE = 1 (default): the staggered quadrant pipeline described in the kernel (half-tile
+// DMA stream six half-tiles ahead, counted vmcnt, raw s_barrier, the two waves of a SIMD one
+// barrier apart): 1.30 PFLOP/s at 8192^3 on random operands, +3...14 % over PIPE = 0 on the
+// workload's shapes.  PIPE = 0: two 64 KB stages, the DMA of k-tile t+1 issued before the 64
+// MFMAs per wave of k-tile t and drained by the __syncthreads() after them (kept for A/B:
+// UENC_GEMM_VARIANT bit 128).
 // ---------------------------------------------------------------------------------------------
 #define BM2 256
 #define BN2 256
 #define T2 512
 
-template <int EPI, int OUT_F32>
+// counted wait on the VM counter (LDS-DMA and global loads / stores in flight): n in {0, 2, 4, 6, 8}
+__device__ __forceinline__ void wait_vmcnt_upto8(int n) {
+    if (n >= 8) __builtin_amdgcn_s_waitcnt(0x0f78);
+    else if (n == 6) __builtin_amdgcn_s_waitcnt(0x0f76);
+    else if (n == 4) __builtin_amdgcn_s_waitcnt(0x0f74);
+    else if (n == 2) __builtin_amdgcn_s_waitcnt(0x0f72);
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+template <int EPI, int OUT_F32, int PIPE>
 __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (A 32 KB + W 32 KB)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -279,46 +292,177 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // DMA geometry: instruction q of a thread fills LDS chunk index L = q * 512 + t  (row L >> 3, slot L & 7)
-    const bf16* asrc[4];
-    const bf16* wsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = q * 64 + (t >> 3), slot = t & 7;
-        const int chunk = slot ^ ((row >> 1) & 7);
-        asrc[q] = (const bf16*)p.A + (long)min(m0 + row, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
-        wsrc[q] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
-    }
     typedef __attribute__((address_space(3))) void lds_void;
-    auto issue = [&](int kt, int stage) {
-        unsigned char* As = smem + stage * 65536;
-        unsigned char* Ws = As + 32768;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (PIPE) {
+        // ---- staggered quadrant pipeline ----
+        // A k-tile buffer (64 KB, two of them) holds four 16 KB HALF-tiles, 128 rows x 128 B each: A0 / A1 = the rows of every wave's
+        // first / second 64 output rows, B0 / B1 = the W rows of every wave's first / second 32 output columns.  A k-tile is four
+        // phases, one output quadrant (64 x 32 per wave, 16 MFMAs) each, in the order (A0,B0) (A0,B1) (A1,B1) (A1,B0); a phase is
+        //     ds_read the operands the quadrant still lacks | issue ONE half-tile DMA | counted vmcnt | s_barrier | 16 MFMAs | s_barrier
+        // and the two wave groups (wm = 0 / 1: the two waves of every SIMD) run one barrier apart, so that one group's MFMAs cover the
+        // other's LDS reads and DMA issue.  The DMA stream runs 6 half-tiles ahead of the reads (half-tile u = 4 T + {A0,B0,B1,A1}; phase
+        // s issues u = s + 6 into the slot read last two or three phases ago) and `vmcnt(8)` after the issue leaves four of them in
+        // flight: u <= s + 2 has landed in this wave, and in all waves after the next barrier pair, i.e. for the reads of phase s + 1.
+        const bf16* src[4][2];              // [A0, B0, B1, A1][q]: DMA instruction q of this thread (row L >> 3, slot L & 7, L = q * 512 + t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lr = q * 64 + (t >> 3), slot = t & 7;
+            const int chunk = slot ^ ((lr >> 1) & 7);
+            const int ra = (lr >> 6) * 128 + (lr & 63), rb = (lr >> 5) * 64 + (lr & 31);
+            src[0][q] = (const bf16*)p.A + (long)min(m0 + ra, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
+            src[3][q] = (const bf16*)p.A + (long)min(m0 + ra + 64, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
+            src[1][q] = p.W + (long)min(n0 + rb, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
+            src[2][q] = p.W + (long)min(n0 + rb + 32, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
+        }
+        // LDS offsets of the half-tiles inside a k-tile buffer, by sequence position o = 0..3 (A0, B0, B1, A1)
+        const int U = 4 * nkt;
+        auto issue = [&](int o, int tile) {          // o compile-time after inlining
+            unsigned char* dst = smem + (tile & 1) * 65536 + (o == 0 ? 0 : o == 1 ? 32768 : o == 2 ? 49152 : 16384) + wave * 1024;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds(src[o][q] + (long)tile * BK, (lds_void*)(dst + q * 8192), 16, 0, 0);
+        };
+        // prologue: half-tiles 0..5 (k-tile 0 and A0, B0 of k-tile 1); A0, B0 of k-tile 0 must have landed everywhere before phase 0
+        issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+        if (U > 4) { issue(0, 1); issue(1, 1); }
+        wait_vmcnt_upto8(U > 4 ? 8 : 4);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();             // the stagger: group 1 runs one barrier behind group 0
+
+        const int aoff = lds_off(wm * 64 + fr, fg), boff = lds_off(wn * 32 + fr, fg);      // row + 16 j keeps (row >> 1) & 7 -> + 2048 j
+        bf16x8 af[4][2], b0[2][2], b1[2][2];
+        for (int T = 0; T < nkt; ++T) {
+            const unsigned char* buf = smem + (T & 1) * 65536;
+            const int s = 4 * T;
+            // phase 1: A0, B0 -> quadrant (0, 0)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b0[i][ks] = *(const bf16x8*)(buf + 32768 + i * 2048 + (boff ^ (ks << 6)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[j][ks] = *(const bf16x8*)(buf + j * 2048 + (aoff ^ (ks << 6)));
+            if (s + 6 < U) issue(2, T + 1);
+            wait_vmcnt_upto8(2 * min(max(U - s - 3, 0), 4));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b0[i][ks], af[j][ks], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: B1 -> quadrant (0, 1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b1[i][ks] = *(const bf16x8*)(buf + 49152 + i * 2048 + (boff ^ (ks << 6)));
+            if (s + 7 < U) issue(3, T + 1);
+            wait_vmcnt_upto8(2 * min(max(U - s - 4, 0), 4));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[2 + i][j] = mfma16(b1[i][ks], af[j][ks], acc[2 + i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: A1 -> quadrant (1, 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[j][ks] = *(const bf16x8*)(buf + 16384 + j * 2048 + (aoff ^ (ks << 6)));
+            if (s + 8 < U) issue(0, T + 2);
+            wait_vmcnt_upto8(2 * min(max(U - s - 5, 0), 4));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[2 + i][4 + j] = mfma16(b1[i][ks], af[j][ks], acc[2 + i][4 + j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 4: (B0 still in registers) -> quadrant (1, 0)
+            if (s + 9 < U) issue(1, T + 2);
+            wait_vmcnt_upto8(2 * min(max(U - s - 6, 0), 4));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][4 + j] = mfma16(b0[i][ks], af[j][ks], acc[i][4 + j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();             // group 0 waits for group 1's last phase
+    } else {
+        // DMA geometry: instruction q of a thread fills LDS chunk index L = q * 512 + t  (row L >> 3, slot L & 7)
+        const bf16* asrc[4];
+        const bf16* wsrc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_global_load_lds(asrc[q] + kt * BK, (lds_void*)(As + (q * 512 + wave * 64) * 16), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(wsrc[q] + kt * BK, (lds_void*)(Ws + (q * 512 + wave * 64) * 16), 16, 0, 0);
+            const int row = q * 64 + (t >> 3), slot = t & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            asrc[q] = (const bf16*)p.A + (long)min(m0 + row, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
+            wsrc[q] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
         }
-    };
+        auto issue = [&](int kt, int stage) {
+            unsigned char* As = smem + stage * 65536;
+            unsigned char* Ws = As + 32768;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_global_load_lds(asrc[q] + kt * BK, (lds_void*)(As + (q * 512 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(wsrc[q] + kt * BK, (lds_void*)(Ws + (q * 512 + wave * 64) * 16), 16, 0, 0);
+            }
+        };
 
-    const int fr = lane & 15, fg = lane >> 4;
-    issue(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();     // waits for this wave's DMA (vmcnt 0), then everyone: tile kt landed, stage (kt+1)&1 is free
-        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-        const unsigned char* As = smem + (kt & 1) * 65536;
-        const unsigned char* Ws = As + 32768;
+        issue(0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();     // waits for this wave's DMA (vmcnt 0), then everyone: tile kt landed, stage (kt+1)&1 is free
+            if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+            const unsigned char* As = smem + (kt & 1) * 65536;
+            const unsigned char* Ws = As + 32768;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], xf[8];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 wf[4], xf[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(Ws + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fg));
+                for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(Ws + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(As + lds_off(wm * 128 + j * 16 + fr, ks * 4 + fg));
+                for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(As + lds_off(wm * 128 + j * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+                    for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+            }
         }
+
     }
 
     // epilogue: four passes of 64 rows through a padded fp32 LDS tile [64][260]; then 8 columns per thread
@@ -410,16 +554,16 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     }
 }
 
-template <int EPI, int OUT_F32>
+template <int EPI, int OUT_F32, int PIPE>
 static int launch_nt256(GemmNT& p, hipStream_t stream) {
     p.tiles_m = (p.M + BM2 - 1) / BM2; p.tiles_n = (p.N + BN2 - 1) / BN2;
     static bool attr_set = false;      // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(T2), 131072, stream, p);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
 }
 
@@ -478,7 +622,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     }
     if (big) {
         int rc = UENC_EINVAL;
-#define LAUNCH2(E, F) rc = launch_nt256<E, F>(p, stream)
+#define LAUNCH2(E, F) rc = (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
         if (c_dtype == UENC_F32) {
             if (epilogue == EPI_NONE) LAUNCH2(EPI_NONE, 1);
             else if (epilogue == EPI_RESIDUAL) LAUNCH2(EPI_RESIDUAL, 1);
