@@ -34,10 +34,16 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-for tag, M, C in [("s1", 262144, 192), ("s2", 65536, 384), ("s3x6", 16384, 768)]:
+import os
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]      # UENC_GEMM_VARIANT values to A/B (bit 256: two-stage TN loop)
+for tag, M, C in [("s1", 262144, 192), ("s2", 65536, 384), ("s3x6", 16384, 768), ("s4", 4096, 1536)]:
     probs = build(M, C, 6 if tag == 's3x6' else 2)
-    for tile, tokens in [(128, 16384), (128, 8192), (128, 4096), (128, 2048), (256, 8192), (256, 4096)]:
+    for tile, tokens in [(128, 4096), (256, 8192), (256, 4096)]:
         d, fl = descs(probs, tile, tokens)
-        t = timeit(lambda: WgradQueue.launch(tile, d, probs[0][0].device))
-        print(f"{tag} tile {tile} tokens/item {tokens:6d}: {sum(x[13] for x in d):5d} items  {t*1e3:8.1f} us  {fl/t/1e9:6.0f} TF/s")
+        row = []
+        for v in variants:
+            os.environ["UENC_GEMM_VARIANT"] = str(v)
+            t = timeit(lambda: WgradQueue.launch(tile, d, probs[0][0].device))
+            row.append(f"v{v}: {t*1e3:8.1f} us {fl/t/1e9:6.0f} TF/s")
+        print(f"{tag} tile {tile} tokens/item {tokens:6d}: {sum(x[13] for x in d):5d} items  " + "  ".join(row), flush=True)
     del probs
