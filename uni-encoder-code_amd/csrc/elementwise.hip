@@ -151,7 +151,18 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restr
         const int tr = local / d.tiles_c, tc = local - tr * d.tiles_c;
         const int r0 = tr * 64, c0 = tc * 64;
         const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-        if (!d.transpose) {
+        if (!d.transpose && (d.cols & 3) == 0 && ((((uintptr_t)d.src) & 15) | (((uintptr_t)d.dst) & 7)) == 0) {
+            // 16 bytes in, 8 bytes out per lane: 16 lanes per 64-column row segment, 16 rows per pass
+            const int cx = c0 + (threadIdx.x & 15) * 4;
+            for (int i = threadIdx.x >> 4; i < 64; i += 16) {
+                const int r = r0 + i;
+                if (r < d.rows && cx < d.cols) {
+                    const float4 v = *(const float4*)(d.src + (long)r * d.cols + cx);
+                    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+                    *(bf16x4*)(d.dst + (long)r * d.cols + cx) = o;
+                }
+            }
+        } else if (!d.transpose) {
             for (int i = ty; i < 64; i += 4) {
                 const int r = r0 + i, c = c0 + tx;
                 if (r < d.rows && c < d.cols) d.dst[(long)r * d.cols + c] = (bf16)d.src[(long)r * d.cols + c];
@@ -163,9 +174,22 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restr
                 tile[i][tx] = (r < d.rows && c < d.cols) ? d.src[(long)r * d.cols + c] : 0.f;
             }
             __syncthreads();
-            for (int i = ty; i < 64; i += 4) {
-                const int c = c0 + i, r = r0 + tx;
-                if (c < d.cols && r < d.rows) d.dst[(long)c * d.rows + r] = (bf16)tile[tx][i];
+            if ((d.rows & 3) == 0 && (((uintptr_t)d.dst) & 7) == 0) {       // 8 bytes out per lane: 16 lanes per 64-row output segment
+                const int rx = (threadIdx.x & 15) * 4;
+                for (int i = threadIdx.x >> 4; i < 64; i += 16) {
+                    const int c = c0 + i, r = r0 + rx;
+                    if (c < d.cols && r < d.rows) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)tile[rx + e][i];
+                        *(bf16x4*)(d.dst + (long)c * d.rows + r) = o;
+                    }
+                }
+            } else {
+                for (int i = ty; i < 64; i += 4) {
+                    const int c = c0 + i, r = r0 + tx;
+                    if (c < d.cols && r < d.rows) d.dst[(long)c * d.rows + r] = (bf16)tile[tx][i];
+                }
             }
         }
     }
