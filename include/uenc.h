@@ -212,6 +212,20 @@ int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, 
                  long dk_bs, long dk_rs, void* dv, long dv_bs, long dv_rs, int B, int H, int Lq, int S, float scale,
                  void* stream);
 
+/* ---- neighbourhood attention 2-D (DiNAT backbone) -------------------------------------------------------------
+ * What natten.NeighborhoodAttention2D computes between its qkv and proj Linear layers (reference call site
+ * model/modeling/backbone/dinat.py:14, 77-79, 94; NATTEN 0.14.4's natten2dqkrpb + softmax + natten2dav -- the wheel is not
+ * part of the reference tree: parity unpinned, restated in oracle/dinat_ref.py).  head_dim is 32.
+ * qkv (B, H, W, 3, nH, 32) bf16 = the qkv Linear's output as is; rpb (nH, 2K-1, 2K-1) fp32 or NULL; out (B, H, W, nH, 32)
+ * bf16; lse (B, nH, H, W) fp32 natural-log log-sum-exp (NULL for inference).  K odd in 3..13; H, W >= K * dilation (the
+ * caller zero-pads smaller inputs first, as NATTEN does); scale = head_dim^-0.5 applied to q.k. */
+int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float* lse, int B, int H, int W, int nH, int K, int dilation,
+                  float scale, void* stream);
+/* dqkv (B, H, W, 3, nH, 32) bf16 overwritten completely; drpb (nH, 2K-1, 2K-1) fp32 ACCUMULATED (may be NULL);
+ * delta_ws: B * nH * H * W floats of scratch. */
+int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out, const void* dout, const float* lse, void* dqkv, float* drpb,
+                  float* delta_ws, int B, int H, int W, int nH, int K, int dilation, float scale, void* stream);
+
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */
 int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile), 1 gemm_tn*, 4 gemm_nt256 */, double* ms_total, double* flops_total, long* launches);

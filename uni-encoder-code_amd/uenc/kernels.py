@@ -161,6 +161,31 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
     return dx
 
 
+def na2d_fwd(qkv: torch.Tensor, rpb: Optional[torch.Tensor], nH: int, ks: int, dilation: int, scale: float, need_lse: bool = True):
+    """Neighbourhood attention on qkv (B, H, W, 3C) bf16 (C = nH * 32) -> out (B, H, W, C) bf16, lse (B, nH, H, W) fp32."""
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and C == nH * 32, "na2d: head_dim must be 32"
+    if rpb is not None:
+        assert rpb.dtype == torch.float32 and rpb.is_contiguous() and tuple(rpb.shape) == (nH, 2 * ks - 1, 2 * ks - 1)
+    out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, nH, H, W), dtype=torch.float32, device=qkv.device) if need_lse else None
+    check(lib.uenc_na2d_fwd(qkv.data_ptr(), ptr(rpb), out.data_ptr(), ptr(lse), B, H, W, nH, ks, dilation, float(scale), stream_ptr()),
+          "na2d_fwd")
+    return out, lse
+
+
+def na2d_bwd(qkv, rpb, out, dout, lse, nH: int, ks: int, dilation: int, scale: float, drpb: Optional[torch.Tensor]):
+    """-> dqkv (B, H, W, 3C) bf16; drpb (nH, 2ks-1, 2ks-1) fp32 is accumulated in place when given."""
+    B, H, W, C3 = qkv.shape
+    assert dout.dtype == torch.bfloat16 and dout.is_contiguous() and out.is_contiguous() and dout.shape == out.shape
+    dqkv = torch.empty_like(qkv)
+    ws = _scratch("na2d_delta", B * nH * H * W * 4, qkv.device)
+    check(lib.uenc_na2d_bwd(qkv.data_ptr(), ptr(rpb), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), ptr(drpb),
+                            ws.data_ptr(), B, H, W, nH, ks, dilation, float(scale), stream_ptr()), "na2d_bwd")
+    return dqkv
+
+
 def relpos_expand(table: torch.Tensor, ws: int):
     """relative_position_bias_table ((2ws-1)^2, nH) fp32 -> dense (nH, NP, NP) in query-major and key-major order."""
     assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] == (2 * ws - 1) ** 2

@@ -1,4 +1,5 @@
 from .backbone.swin import D2SwinTransformer
+from .backbone.dinat import D2DiNAT
 from .pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
 from .pixel_decoder.fpn import build_pixel_decoder
 from .transformer_decoder.oneformer_transformer_decoder import ContrastiveMultiScaleMaskedTransformerDecoder

@@ -14,6 +14,7 @@ import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+import torch.nn.functional as F
 
 from . import kernels as K
 
@@ -988,3 +989,178 @@ class Conv3x3Fn(torch.autograd.Function):
 def conv3x3(x_nhwc, weight):
     """x (B, H, W, Cin) bf16|fp32 channels-last -> (B, H*W, Cout) fp32."""
     return Conv3x3Fn.apply(x_nhwc, weight)
+
+
+# --------------------------------------------------------------------------------------------
+# DiNAT (SURVEY.md §8a A9): neighbourhood attention, the whole NATLayer, the 3x3 stride-2 convolutions
+# --------------------------------------------------------------------------------------------
+class NA2DFn(torch.autograd.Function):
+    """natten2dqkrpb + softmax + natten2dav of natten.NeighborhoodAttention2D (reference call site backbone/dinat.py:77-79) on the
+    qkv Linear's output (B, H, W, 3C) bf16 -> (B, H, W, C) bf16.  H, W >= ks * dilation (the module pads first, like NATTEN)."""
+
+    @staticmethod
+    def forward(ctx, qkv, rpb, nH, ks, dilation, scale):
+        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        rp = None if rpb is None else rpb.detach().float().contiguous()
+        out, lse = K.na2d_fwd(qkv, rp, nH, ks, dilation, scale)
+        ctx.save_for_backward(qkv, rpb, out, lse)
+        ctx.cfg = (nH, ks, dilation, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, rpb, out, lse = ctx.saved_tensors
+        nH, ks, dilation, scale = ctx.cfg
+        dout = dout if dout.dtype == BF16 else dout.to(BF16)
+        train = rpb is not None and rpb.requires_grad
+        dqkv = K.na2d_bwd(qkv, None if rpb is None else rpb.detach().float().contiguous(), out, dout.contiguous(), lse, nH, ks, dilation, scale,
+                          grad_buf(rpb) if train else None)
+        if train:
+            _notify(rpb)
+        return dqkv, None, None, None, None, None
+
+
+def na2d(qkv, rpb, nH: int, ks: int, dilation: int, scale: float):
+    return NA2DFn.apply(qkv, rpb, nH, ks, dilation, scale)
+
+
+class NATLayerFn(torch.autograd.Function):
+    """One whole NATLayer without layer scale (reference backbone/dinat.py:90-97): LN1 -> qkv -> neighbourhood attention ->
+    proj (+x) -> LN2 -> fc1 + GELU -> fc2 (+x), the same kernel sequence as ops.SwinBlockFn with uenc_na2d in the middle.
+    x is the fp32 residual stream (B, H, W, C), H, W >= ks * dilation."""
+
+    @staticmethod
+    def forward(ctx, x, nH, ks, dilation, scale, g1, b1, wqkv, bqkv, rpb, wproj, bproj, g2, b2, w1, bb1, w2, bb2):
+        B, H, W, C = x.shape
+        M = B * H * W
+        x2 = x.reshape(M, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        xn, _, st1 = K.layernorm_fwd(x2, g1.detach(), b1.detach(), out_dtype=BF16)
+        qkv = K.gemm_nt(xn, CACHE.mat(wqkv), bias=None if bqkv is None else bqkv.detach())
+        rp = rpb.detach().float().contiguous()
+        attn, lse = K.na2d_fwd(qkv.view(B, H, W, 3 * C), rp, nH, ks, dilation, scale)
+        x1 = K.gemm_nt(attn.view(M, C), CACHE.mat(wproj), bias=bproj.detach(), epilogue=K.EPI_RESIDUAL, aux=x2, out_dtype=F32)
+        xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
+        pre = torch.empty((M, w1.shape[0]), dtype=BF16, device=x.device)
+        h = K.gemm_nt(xn2, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_GELU, aux_out=pre)
+        x2o = K.gemm_nt(h, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=x1, out_dtype=F32)
+        ctx.save_for_backward(x2, st1, xn, qkv, rp, lse, attn, x1, st2, xn2, pre, h,
+                              g1, b1, wqkv, bqkv, rpb, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
+        ctx.geom = (B, H, W, C, nH, ks, dilation, scale)
+        return x2o.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dxo):
+        (x2, st1, xn, qkv, rp, lse, attn, x1, st2, xn2, pre, h,
+         g1, b1, wqkv, bqkv, rpb, wproj, bproj, g2, b2, w1, bb1, w2, bb2) = ctx.saved_tensors
+        B, H, W, C, nH, ks, dilation, scale = ctx.geom
+        M = B * H * W
+        d2 = dxo.reshape(M, C)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        if d2.dtype != F32:
+            d2 = d2.float()
+        train = wqkv.requires_grad
+        d2h = _twin(d2)
+        if d2h is None:
+            d2h = K.cast_bf16(d2)
+        dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)
+        if train:
+            _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
+        dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))
+        if train:
+            _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
+        tw = []
+        dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
+                              dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
+        dx1h = tw[0]
+        dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))
+        if train:
+            _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
+        dqkv = K.na2d_bwd(qkv.view(B, H, W, 3 * C), rp, attn, dattn.view(B, H, W, C), lse, nH, ks, dilation, scale,
+                          grad_buf(rpb) if (train and rpb.requires_grad) else None)
+        dqkv2 = dqkv.view(M, 3 * C)
+        dxn = K.gemm_nt(dqkv2, CACHE.mat_t(wqkv))
+        if train:
+            _tn(dqkv2, xn, grad_buf(wqkv), None if bqkv is None else grad_buf(bqkv), (wqkv, bqkv))
+        tw = []
+        dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
+                             dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None, twin=tw)
+        _register_twin(dx, tw[0])
+        if train:
+            _tn_notify(g1, b1, rpb, g2, b2)
+        return (dx.view(B, H, W, C),) + (None,) * 17
+
+
+def nat_layer(x, nH, ks, dilation, scale, params: Sequence[torch.Tensor]):
+    return NATLayerFn.apply(x, nH, ks, dilation, scale, *params)
+
+
+class ConvS2Fn(torch.autograd.Function):
+    """3x3 stride-2 padding-1 convolution on a channels-last map (ConvTokenizer / ConvDownsampler, reference backbone/dinat.py:17-45)
+    as patch gather + MFMA GEMM: x (B, H, W, Cin) -> (B, Ho, Wo, Cout) fp32, Ho = ceil(H / 2).  The patch matrix is gathered with
+    strided slices (data movement only); forward, input gradient and weight gradient are the library's GEMMs."""
+
+    @staticmethod
+    def _patches(x16, Ho, Wo, Kp):
+        B, H, W, C = x16.shape
+        xp = F.pad(x16, (0, 0, 1, 2 * Wo - W, 1, 2 * Ho - H))            # pad 1 left / top; right / bottom up to the last tap
+        taps = [xp[:, dy:dy + 2 * Ho:2, dx:dx + 2 * Wo:2, :] for dy in range(3) for dx in range(3)]
+        if Kp > 9 * C:
+            taps.append(x16.new_zeros((B, Ho, Wo, Kp - 9 * C)))
+        return torch.cat(taps, dim=-1).reshape(B * Ho * Wo, Kp)
+
+    @staticmethod
+    def _wmat(weight, Kp, transposed):
+        def make():
+            w = weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+            w = F.pad(w, (0, Kp - w.shape[1], 0, -weight.shape[0] % 8)).contiguous()
+            return K.cast_transpose_bf16(w) if transposed else K.cast_bf16(w)
+        return CACHE._get(weight, "s2t" if transposed else "s2", make)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, C = x.shape
+        Co = weight.shape[0]
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        Kp = -(-9 * C // 8) * 8
+        col = ConvS2Fn._patches(x if x.dtype == BF16 else x.to(BF16), Ho, Wo, Kp)
+        Np = -(-Co // 8) * 8
+        out = K.gemm_nt(col, ConvS2Fn._wmat(weight, Kp, False), bias=_bias_pad(bias, Np), out_dtype=F32)
+        ctx.save_for_backward(col, weight, bias)
+        ctx.shape = (B, H, W, C, Ho, Wo, Kp, Np)
+        ctx.in_dtype = x.dtype
+        return out[:, :Co].reshape(B, Ho, Wo, Co) if Np != Co else out.view(B, Ho, Wo, Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, weight, bias = ctx.saved_tensors
+        B, H, W, C, Ho, Wo, Kp, Np = ctx.shape
+        Co = weight.shape[0]
+        dy2 = dy.reshape(B * Ho * Wo, Co)
+        dy2 = K.cast_bf16(dy2.float().contiguous()) if dy2.dtype != BF16 else dy2.contiguous()
+        if Np != Co:
+            dy2 = F.pad(dy2, (0, Np - Co))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = K.gemm_nt(dy2, ConvS2Fn._wmat(weight, Kp, True), out_dtype=F32).view(B, Ho, Wo, Kp)
+            dxp = dcol.new_zeros((B, 2 * Ho + 2, 2 * Wo + 2, C))
+            for t in range(9):                                            # adjoint of the strided gather
+                dyy, dxx = divmod(t, 3)
+                dxp[:, dyy:dyy + 2 * Ho:2, dxx:dxx + 2 * Wo:2, :] += dcol[..., t * C:(t + 1) * C]
+            dx = dxp[:, 1:1 + H, 1:1 + W, :].to(ctx.in_dtype)
+        if weight.requires_grad:
+            dw = torch.zeros((Np, Kp), dtype=F32, device=dy.device)
+            db = torch.zeros((Np,), dtype=F32, device=dy.device) if bias is not None else None
+            K.gemm_tn(dy2, col, dw, db)
+            grad_buf(weight).add_(dw[:Co, :9 * C].view(Co, 3, 3, C).permute(0, 3, 1, 2))
+            if bias is not None:
+                grad_buf(bias).add_(db[:Co])
+            _tn_notify(weight, bias)
+        return dx, None, None
+
+
+def conv3x3_s2(x_nhwc, weight, bias=None):
+    """x (B, H, W, Cin) channels-last -> (B, ceil(H/2), ceil(W/2), Cout) fp32."""
+    return ConvS2Fn.apply(x_nhwc, weight, bias)
