@@ -120,11 +120,13 @@ def neighborhood_attention(x: Tensor, sd: SD, p: str, nH: int, ks: int, d: int) 
     return _lin(o, sd, p + ".proj")
 
 
-def nat_layer(x: Tensor, sd: SD, p: str, nH: int, ks: int, d: int) -> Tensor:
-    """NATLayer.forward without layer scale (dinat.py:90-97; DropPath / dropout are identity in eval)."""
-    x = x + neighborhood_attention(_ln(x, sd, p + ".norm1"), sd, p + ".attn", nH, ks, d)
+def nat_layer(x: Tensor, sd: SD, p: str, nH: int, ks: int, d: int, branch_scale=None) -> Tensor:
+    """NATLayer.forward without layer scale (dinat.py:90-97).  branch_scale = None: eval (DropPath identity); else two (B,)
+    tensors of timm DropPath's per-sample multipliers for the attention and the MLP branch (training mode, dinat.py:95-96)."""
+    a = neighborhood_attention(_ln(x, sd, p + ".norm1"), sd, p + ".attn", nH, ks, d)
+    x = x + (a if branch_scale is None else a * branch_scale[0].view(-1, 1, 1, 1))
     h = _lin(F.gelu(_lin(_ln(x, sd, p + ".norm2"), sd, p + ".mlp.fc1")), sd, p + ".mlp.fc2")
-    return x + h
+    return x + (h if branch_scale is None else h * branch_scale[1].view(-1, 1, 1, 1))
 
 
 def dinat_backbone(img: Tensor, sd: SD, cfg: DiNATCfg, prefix: str = "backbone.") -> Dict[str, Tensor]:

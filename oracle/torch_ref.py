@@ -174,11 +174,13 @@ def window_attention(xn: Tensor, sd: SD, p: str, H: int, W: int, ws: int, shift:
 
 
 def swin_block(x: Tensor, sd: SD, p: str, H: int, W: int, ws: int, shift: int, nH: int,
-               qk_scale=None) -> Tensor:
-    """backbone/swin.py:235-295 (eval mode: DropPath = identity)."""
-    x = x + window_attention(_ln(x, sd, p + ".norm1"), sd, p + ".attn", H, W, ws, shift, nH, qk_scale)
-    h = F.gelu(_lin(_ln(x, sd, p + ".norm2"), sd, p + ".mlp.fc1"))
-    return x + _lin(h, sd, p + ".mlp.fc2")
+               qk_scale=None, branch_scale=None) -> Tensor:
+    """backbone/swin.py:235-295.  branch_scale = None: eval mode, DropPath = identity; else two (B,) tensors, the per-sample
+    multipliers timm's DropPath applies to the attention and to the MLP branch in training (0 or 1 / keep_prob: swin.py:279, 289)."""
+    a = window_attention(_ln(x, sd, p + ".norm1"), sd, p + ".attn", H, W, ws, shift, nH, qk_scale)
+    x = x + (a if branch_scale is None else a * branch_scale[0].view(-1, 1, 1))
+    h = _lin(F.gelu(_lin(_ln(x, sd, p + ".norm2"), sd, p + ".mlp.fc1")), sd, p + ".mlp.fc2")
+    return x + (h if branch_scale is None else h * branch_scale[1].view(-1, 1, 1))
 
 
 def patch_merging(x: Tensor, sd: SD, p: str, H: int, W: int) -> Tensor:

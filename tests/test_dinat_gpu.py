@@ -155,3 +155,35 @@ def test_d2dinat_registry_and_config(U):
     add_dinat_config(cfg2)
     with pytest.raises(IndexError):
         BACKBONE_REGISTRY.get("D2DiNAT")(cfg2, None)
+
+
+@pytest.mark.parametrize("H,W", [(12, 20), (4, 5)])
+def test_nat_layer_drop_path_training(U, H, W):
+    """Training-mode stochastic depth of a NATLayer (dinat.py:95-96) with given per-sample multipliers, fused path (12 x 20) and
+    NATTEN's padding path (4 x 5 < 3 * 2), forward and backward against the oracle layer with the same multipliers."""
+    from oracle import dinat_ref as D, fill
+    from uenc import ops
+    from uenc.modeling.backbone.dinat import NATLayer
+    ops.CACHE.invalidate()
+    C, nH, ks, d, B = 64, 2, 3, 2, 3
+    layer = NATLayer(C, nH, ks, d, mlp_ratio=2.0, drop_path=0.2).cuda()
+    p = "backbone.levels.0.blocks.0"
+    fill.fill_module(layer, p + ".")
+    sd = {p + "." + k: v.detach().cpu().clone().requires_grad_() for k, v in layer.state_dict().items()}
+    x = _rand(B, H, W, C, seed=11).cuda().requires_grad_()
+    dy = _rand(B, H, W, C, seed=12)
+    layer.train()
+    torch.manual_seed(3)
+    s1, s2 = ops.drop_path_scales(B, 0.2), ops.drop_path_scales(B, 0.2)
+    assert all(v in (0.0, 1 / 0.8) for v in s1 + s2)
+    torch.manual_seed(3)
+    y = layer(x)
+    y.backward(dy.cuda())
+    ops.flush_wgrads()
+    x2 = x.detach().cpu().requires_grad_()
+    y2 = D.nat_layer(x2, sd, p, nH, ks, d, branch_scale=(torch.tensor(s1), torch.tensor(s2)))
+    y2.backward(dy)
+    assert rel(y, y2) < 1.5e-2 and rel(x.grad, x2.grad) < 2e-2
+    bad = [(n, rel(q.grad, sd[p + "." + n].grad)) for n, q in layer.named_parameters() if rel(q.grad, sd[p + "." + n].grad) > 5e-2]
+    assert not bad, bad
+    ops.CACHE.invalidate()

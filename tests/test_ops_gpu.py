@@ -401,3 +401,41 @@ def test_wgrad_queue_small_grouped(ops):
         assert float((gw.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
         refb = gb0.double() + d16.sum(0)
         assert float((gb.double() - refb).abs().max()) < 2e-3 * float(refb.abs().max())
+
+
+def test_swin_block_drop_path_training(ops):
+    """Training-mode stochastic depth (timm DropPath on both residual branches, reference backbone/swin.py:279, 289): with given
+    per-sample multipliers the fused block equals the oracle block with the same multipliers, forward and backward, including a
+    dropped branch (multiplier 0) whose parameters must receive no gradient contribution from that sample."""
+    from oracle import torch_ref as T, fill
+    from uenc.modeling.backbone.swin import SwinTransformerBlock
+    ops.CACHE.invalidate()
+    C, nH, ws, H, W, B = 64, 2, 4, 8, 12, 3
+    blk = SwinTransformerBlock(C, nH, ws, 2, drop_path=0.25).cuda()
+    fill.fill_module(blk, "backbone.layers.0.blocks.1.")
+    blk.H, blk.W = H, W
+    sd = {"backbone.layers.0.blocks.1." + k: v.detach().cpu().clone().requires_grad_() for k, v in blk.state_dict().items()
+          if "relative_position_index" not in k}
+    s1, s2 = [1 / 0.75, 0.0, 1 / 0.75], [0.0, 1 / 0.75, 1 / 0.75]
+    x = _r(B, H * W, C, seed=3).requires_grad_()
+    dy = _r(B, H * W, C, seed=4)
+    y = ops.swin_block(x, H, W, ws, 2, nH, blk.attn.scale, blk._params(), (s1, s2))
+    y.backward(dy)
+    ops.flush_wgrads()
+    x2 = x.detach().cpu().requires_grad_()
+    y2 = T.swin_block(x2, sd, "backbone.layers.0.blocks.1", H, W, ws, 2, nH, branch_scale=(torch.tensor(s1), torch.tensor(s2)))
+    y2.backward(dy.cpu())
+    _check("y", y.cpu(), y2, 1.5e-2); _check("dx", x.grad.cpu(), x2.grad, 2e-2)
+    for name, p in blk.named_parameters():
+        _check(name, p.grad.cpu(), sd["backbone.layers.0.blocks.1." + name].grad, 4e-2)
+    # the module draws its multipliers from torch's CPU generator in training mode only
+    blk.train()
+    torch.manual_seed(7)
+    want = (ops.drop_path_scales(B, 0.25), ops.drop_path_scales(B, 0.25))
+    torch.manual_seed(7)
+    yt = blk(x.detach())
+    _check("train", yt, ops.swin_block(x.detach(), H, W, ws, 2, nH, blk.attn.scale, blk._params(), want), 1e-6)
+    assert all(v in (0.0, 1 / 0.75) for v in want[0] + want[1])
+    blk.eval()
+    _check("eval", blk(x.detach()), ops.swin_block(x.detach(), H, W, ws, 2, nH, blk.attn.scale, blk._params()), 1e-6)
+    ops.CACHE.invalidate()

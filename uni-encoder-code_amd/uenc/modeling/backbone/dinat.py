@@ -12,8 +12,9 @@ LayerNorm, bf16 MFMA GEMMs with bias / GELU / residual epilogues and the neighbo
 fp32 channels-last residual stream; the 3x3 stride-2 convolutions of the tokenizer and the downsamplers are patch
 gathers + the same GEMMs (`ops.ConvS2Fn`).
 
-Not reproduced: stochastic depth and dropout act as identity (as in the Swin path: the shipped configs evaluate
-only); `layer_scale` (never passed by `D2DiNAT`, `dinat.py:246-255`) raises.
+Stochastic depth is applied in training mode as in the Swin path (`ops.drop_path_scales`).  Not reproduced: the
+dropout layers (rate 0 in the shipped config, config.py:235-236); `layer_scale` (never passed by `D2DiNAT`,
+`dinat.py:246-255`) raises.
 """
 import torch
 import torch.nn as nn
@@ -117,6 +118,7 @@ class NATLayer(nn.Module):
         self.norm1 = norm_layer(dim)
         self.attn = NeighborhoodAttention2D(dim, kernel_size=kernel_size, dilation=dilation, num_heads=num_heads, qkv_bias=qkv_bias,
                                             qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path_rate = drop_path
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.layer_scale = False
@@ -124,16 +126,24 @@ class NATLayer(nn.Module):
     def forward(self, x):
         """x (B, H, W, C) fp32 residual stream."""
         a = self.attn
-        _, H, W, _ = x.shape
+        B, H, W, _ = x.shape
+        dp = None
+        if self.training and self.drop_path_rate > 0.0:      # stochastic depth: one draw per residual branch and sample (dinat.py:95-96)
+            dp = (ops.drop_path_scales(B, self.drop_path_rate), ops.drop_path_scales(B, self.drop_path_rate))
         if H >= a.window_size and W >= a.window_size and a.rpb is not None and a.qkv.bias is not None:
             return ops.nat_layer(x, a.num_heads, a.kernel_size, a.dilation, a.scale,
                                  [self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.rpb, a.proj.weight, a.proj.bias,
                                   self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
-                                  self.mlp.fc2.bias])
+                                  self.mlp.fc2.bias], dp)
         # small maps (NATTEN's padding path) and bias-free variants: the same kernels, composed op by op
-        x = a(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, out_dtype=torch.bfloat16), residual=x)
+        if dp is None:
+            x = a(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, out_dtype=torch.bfloat16), residual=x)
+            h = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, out_dtype=torch.bfloat16)
+            return ops.mlp(h, [self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias], act="gelu", residual=x)
+        s1, s2 = (torch.tensor(v, device=x.device).view(B, 1, 1, 1) for v in dp)
+        x = x + s1 * a(ops.layer_norm(x, self.norm1.weight, self.norm1.bias, out_dtype=torch.bfloat16)).float()
         h = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, out_dtype=torch.bfloat16)
-        return ops.mlp(h, [self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias], act="gelu", residual=x)
+        return x + s2 * ops.mlp(h, [self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias], act="gelu").float()
 
 
 class NATBlock(nn.Module):

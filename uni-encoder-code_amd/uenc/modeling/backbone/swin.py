@@ -11,8 +11,11 @@ fused kernels — LayerNorm, bf16 MFMA GEMMs with bias/GELU/residual epilogues a
 attention kernel that folds pad / roll / partition / reverse / crop into addressing — instead of the
 reference's ~40 ATen calls and 4-6 full-tensor copies per block (swin.py:250-289).
 
-Not reproduced (documented gaps): stochastic depth and dropout in training mode act as
-identity (the shipped config evaluates only, `train_net.py:283`); APE; activation checkpointing.
+Stochastic depth (DropPath) is applied in training mode as per-sample scales of the two residual
+branches (`ops.drop_path_scales`; drawn from torch's CPU generator, so the random stream differs from the
+reference's device-side draw).  Not reproduced (documented gaps): the MLP / attention dropout
+layers (rate 0 in every shipped config: `DROP_RATE`, `ATTN_DROP_RATE` = 0, config.py:192-214); APE;
+activation checkpointing.
 """
 import numpy as np
 import torch
@@ -89,8 +92,11 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         H, W = self.H, self.W
         assert L == H * W, "input feature has wrong size"
+        dp = None
+        if self.training and self.drop_path_rate > 0.0:      # stochastic depth: one draw per residual branch and sample (swin.py:279, 289)
+            dp = (ops.drop_path_scales(B, self.drop_path_rate), ops.drop_path_scales(B, self.drop_path_rate))
         return ops.swin_block(x.float(), H, W, self.window_size, self.shift_size, self.num_heads, self.attn.scale,
-                              self._params())
+                              self._params(), dp)
 
 
 class PatchMerging(nn.Module):

@@ -584,13 +584,48 @@ def layer_norm(x, gamma, beta, *, res=None, out_dtype=F32, eps=1e-5):
 # --------------------------------------------------------------------------------------------
 # Swin block: LN1 -> qkv -> fused window attention -> proj(+x) -> LN2 -> fc1+GELU -> fc2(+x)
 # --------------------------------------------------------------------------------------------
+def drop_path_scales(B: int, drop_prob: float):
+    """timm DropPath (reference backbone/swin.py:8, 231, 279, 289) for one residual branch: per-sample multipliers
+    floor(keep_prob + U[0,1)) / keep_prob as python floats.  Drawn from torch's CPU generator: no device sync."""
+    keep = 1.0 - drop_prob
+    return [float(v) / keep for v in torch.floor(keep + torch.rand(B)).tolist()]
+
+
+def _branch_gemm(h, w16, bias, res, out_rows, scales):
+    """out = res + scale_b * (h @ w^T + bias) per sample b (rows split evenly): the residual epilogue with alpha = scale_b."""
+    M = h.shape[0]
+    if scales is None:
+        return K.gemm_nt(h, w16, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=F32)
+    out = torch.empty((M, out_rows), dtype=F32, device=h.device)
+    B = len(scales)
+    L = M // B
+    for b, sc in enumerate(scales):
+        rows = slice(b * L, (b + 1) * L)
+        if sc == 0.0:
+            out[rows].copy_(res[rows])                 # dropped branch: the residual passes through
+        else:
+            K.gemm_nt(h[rows], w16, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res[rows], out=out[rows], alpha=sc)
+    return out
+
+
+def _scaled_rows(g16, scales):
+    """bf16 copy of a (M, C) gradient with sample b's rows multiplied by scale_b (the backward of the DropPath scaling)."""
+    if scales is None:
+        return g16
+    B = len(scales)
+    sc = torch.tensor(scales, dtype=torch.float32).to(g16.device, non_blocking=True)
+    return (g16.view(B, -1, g16.shape[-1]).float() * sc.view(B, 1, 1)).to(BF16).view(g16.shape)
+
+
 class SwinBlockFn(torch.autograd.Function):
     """One whole SwinTransformerBlock (reference backbone/swin.py:235-295) as 7 kernels forward and
-    13 backward, all HIP.  x is the fp32 residual stream (B, L, C)."""
+    13 backward, all HIP.  x is the fp32 residual stream (B, L, C).  dp: None (eval) or (scales_attn, scales_mlp), the
+    per-sample DropPath multipliers of the two residual branches in training mode (`drop_path_scales`)."""
 
     @staticmethod
-    def forward(ctx, x, H, W, ws, shift, nH, scale, g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2):
+    def forward(ctx, x, H, W, ws, shift, nH, scale, dp, g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2):
         B, L, C = x.shape
+        s1, s2 = dp if dp is not None else (None, None)
         M = B * L
         x2 = x.reshape(M, C)
         if not x2.is_contiguous():
@@ -599,11 +634,12 @@ class SwinBlockFn(torch.autograd.Function):
         qkv = K.gemm_nt(xn, CACHE.mat(wqkv), bias=bqkv.detach())
         bias_q, bias_k = K.relpos_expand(table.detach().contiguous(), ws)
         attn = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, ws, shift, scale)
-        x1 = K.gemm_nt(attn.view(M, C), CACHE.mat(wproj), bias=bproj.detach(), epilogue=K.EPI_RESIDUAL, aux=x2, out_dtype=F32)
+        x1 = _branch_gemm(attn.view(M, C), CACHE.mat(wproj), bproj.detach(), x2, C, s1)
         xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
         pre = torch.empty((M, w1.shape[0]), dtype=BF16, device=x.device)
         h = K.gemm_nt(xn2, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_GELU, aux_out=pre)
-        x2o = K.gemm_nt(h, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=x1, out_dtype=F32)
+        x2o = _branch_gemm(h, CACHE.mat(w2), bb2.detach(), x1, C, s2)
+        ctx.dp = (s1, s2)
         ctx.save_for_backward(x2, st1, xn, qkv, bias_q, bias_k, attn, x1, st2, xn2, pre, h,
                               g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
         ctx.geom = (B, L, C, H, W, ws, shift, nH, scale)
@@ -620,9 +656,11 @@ class SwinBlockFn(torch.autograd.Function):
             d2 = d2.contiguous()
         train = wqkv.requires_grad
         # MLP branch (bf16 copy of the incoming stream gradient: the dgrad / wgrad GEMMs read bf16 operands)
+        s1, s2 = ctx.dp
         d2h = _twin(d2)                                     # written by the LayerNorm backward that produced this gradient
         if d2h is None:
             d2h = K.cast_bf16(d2)
+        d2h = _scaled_rows(d2h, s2)                         # DropPath: the MLP branch sees scale_b * gradient
         dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)             # (M, 4C) d(pre-GELU)
         if train:
             _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
@@ -633,7 +671,7 @@ class SwinBlockFn(torch.autograd.Function):
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
         # attention branch
-        dx1h = tw[0]
+        dx1h = _scaled_rows(tw[0], s1)
         dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))                                        # (M, C) bf16
         if train:
             _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
@@ -651,11 +689,11 @@ class SwinBlockFn(torch.autograd.Function):
         _register_twin(dx, tw[0])                           # the previous block's backward starts from dx in bf16
         if train:
             _tn_notify(g1, b1, table, g2, b2)
-        return (dx.view(B, L, C),) + (None,) * 19
+        return (dx.view(B, L, C),) + (None,) * 20
 
 
-def swin_block(x, H, W, ws, shift, nH, scale, params: Sequence[torch.Tensor]):
-    return SwinBlockFn.apply(x, H, W, ws, shift, nH, scale, *params)
+def swin_block(x, H, W, ws, shift, nH, scale, params: Sequence[torch.Tensor], dp=None):
+    return SwinBlockFn.apply(x, H, W, ws, shift, nH, scale, dp, *params)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1027,11 +1065,12 @@ def na2d(qkv, rpb, nH: int, ks: int, dilation: int, scale: float):
 class NATLayerFn(torch.autograd.Function):
     """One whole NATLayer without layer scale (reference backbone/dinat.py:90-97): LN1 -> qkv -> neighbourhood attention ->
     proj (+x) -> LN2 -> fc1 + GELU -> fc2 (+x), the same kernel sequence as ops.SwinBlockFn with uenc_na2d in the middle.
-    x is the fp32 residual stream (B, H, W, C), H, W >= ks * dilation."""
+    x is the fp32 residual stream (B, H, W, C), H, W >= ks * dilation.  dp: as in SwinBlockFn (DropPath scales, training mode)."""
 
     @staticmethod
-    def forward(ctx, x, nH, ks, dilation, scale, g1, b1, wqkv, bqkv, rpb, wproj, bproj, g2, b2, w1, bb1, w2, bb2):
+    def forward(ctx, x, nH, ks, dilation, scale, dp, g1, b1, wqkv, bqkv, rpb, wproj, bproj, g2, b2, w1, bb1, w2, bb2):
         B, H, W, C = x.shape
+        s1, s2 = dp if dp is not None else (None, None)
         M = B * H * W
         x2 = x.reshape(M, C)
         if not x2.is_contiguous():
@@ -1040,11 +1079,12 @@ class NATLayerFn(torch.autograd.Function):
         qkv = K.gemm_nt(xn, CACHE.mat(wqkv), bias=None if bqkv is None else bqkv.detach())
         rp = rpb.detach().float().contiguous()
         attn, lse = K.na2d_fwd(qkv.view(B, H, W, 3 * C), rp, nH, ks, dilation, scale)
-        x1 = K.gemm_nt(attn.view(M, C), CACHE.mat(wproj), bias=bproj.detach(), epilogue=K.EPI_RESIDUAL, aux=x2, out_dtype=F32)
+        x1 = _branch_gemm(attn.view(M, C), CACHE.mat(wproj), bproj.detach(), x2, C, s1)
         xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
         pre = torch.empty((M, w1.shape[0]), dtype=BF16, device=x.device)
         h = K.gemm_nt(xn2, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_GELU, aux_out=pre)
-        x2o = K.gemm_nt(h, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=x1, out_dtype=F32)
+        x2o = _branch_gemm(h, CACHE.mat(w2), bb2.detach(), x1, C, s2)
+        ctx.dp = (s1, s2)
         ctx.save_for_backward(x2, st1, xn, qkv, rp, lse, attn, x1, st2, xn2, pre, h,
                               g1, b1, wqkv, bqkv, rpb, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
         ctx.geom = (B, H, W, C, nH, ks, dilation, scale)
@@ -1062,9 +1102,11 @@ class NATLayerFn(torch.autograd.Function):
         if d2.dtype != F32:
             d2 = d2.float()
         train = wqkv.requires_grad
+        s1, s2 = ctx.dp
         d2h = _twin(d2)
         if d2h is None:
             d2h = K.cast_bf16(d2)
+        d2h = _scaled_rows(d2h, s2)
         dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)
         if train:
             _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
@@ -1074,7 +1116,7 @@ class NATLayerFn(torch.autograd.Function):
         tw = []
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
-        dx1h = tw[0]
+        dx1h = _scaled_rows(tw[0], s1)
         dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))
         if train:
             _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
@@ -1090,11 +1132,11 @@ class NATLayerFn(torch.autograd.Function):
         _register_twin(dx, tw[0])
         if train:
             _tn_notify(g1, b1, rpb, g2, b2)
-        return (dx.view(B, H, W, C),) + (None,) * 17
+        return (dx.view(B, H, W, C),) + (None,) * 18
 
 
-def nat_layer(x, nH, ks, dilation, scale, params: Sequence[torch.Tensor]):
-    return NATLayerFn.apply(x, nH, ks, dilation, scale, *params)
+def nat_layer(x, nH, ks, dilation, scale, params: Sequence[torch.Tensor], dp=None):
+    return NATLayerFn.apply(x, nH, ks, dilation, scale, dp, *params)
 
 
 class ConvS2Fn(torch.autograd.Function):
