@@ -20,7 +20,7 @@ shapes = [
     (86016, 256, 256, "enc proj"), (86016, 1024, 256, "enc ffn1"), (86016, 256, 1024, "enc ffn2"),
     (262144, 256, 256, "kv proj"), (8192, 8192, 8192, "square 8k"),
 ]
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,128").split(",")]
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,128").split(",")]      # bit 128: two-stage loop, 512: no 192-wide tiles
 print(f"{'shape':28s} " + " ".join(f"{'v' + str(v) + ' bf16/res/gelu/dgelu':>30s}" for v in variants) + "   (TFLOP/s)")
 for M, N, Kd, tag in shapes:
     a = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
