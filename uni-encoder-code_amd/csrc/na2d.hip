@@ -23,6 +23,7 @@ struct Na2d {
     const bf16* dout; bf16* dqkv; float* drpb; float* delta;
     int B, H, W, nH, d;
     float scale;
+    int hh_max, hw_max;      // bwd_kv tiled: LDS halo extents (class positions) for this launch
 };
 
 struct AxisWin { int start, r, pb0; };       // first class position of the window, residue, bias index of slot 0
@@ -36,9 +37,24 @@ __device__ __forceinline__ AxisWin axis_win(int t, int len, int d, int K) {
     return a;
 }
 
-__device__ __forceinline__ float quad_sum(float v) {       // over the 4 lanes of a pixel
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
+// Cross-lane sums on DPP (VALU data-parallel primitives): __shfl_xor compiles to ds_bpermute, which goes through the LDS
+// crossbar and competes with the halo reads of the tiled kernels.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {       // over the 4 lanes of a pixel: quad_perm [1,0,3,2], then [2,3,0,1]
+    v = dpp_add<0xB1, 0xf>(v);
+    v = dpp_add<0x4E, 0xf>(v);
+    return v;
+}
+// sum over the wave's 16 pixels of a value that is equal in the 4 lanes of each pixel; valid in lane 63 only:
+// row_shr:4, row_shr:8 (lanes 12..15 of each 16-lane row hold the row's sum), row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3
+__device__ __forceinline__ float pixels_sum_lane63(float v) {
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
     return v;
 }
 
@@ -110,6 +126,99 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(Na2d p) {
     if (c8 == 0 && p.lse) p.lse[(((long)b * p.nH + h) * p.H + y) * p.W + x] = (m + __log2f(l)) * LN2;
 }
 
+// ---- LDS-tiled forward ----
+// One workgroup = one head of one image, one residue class (y mod d, x mod d), a tile of 8 x 16 class positions.  The k and v
+// rows of the tile's halo (the union of its windows: at most 14 x 22 class positions, 39 KB as bf16) are staged in LDS once --
+// 2.4x the tile's own pixels instead of the 49 window slots per pixel the direct kernel pulls through L1 -- and the k x k loop
+// reads them with conflict-free 16-byte LDS loads (a wave = 16 adjacent pixels = 1 KB contiguous).  q.k runs on v_dot2_f32_bf16.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dot8_bf16(const bf16x8& a, const bf16x8& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        bf16x2v x, y;
+        x[0] = a[c]; x[1] = a[c + 1]; y[0] = b[c]; y[1] = b[c + 1];
+        s = __builtin_amdgcn_fdot2_f32_bf16(x, y, s, false);
+    }
+    return s;
+}
+
+#define NA_TH 8
+#define NA_TW 16
+
+// grid (tiles_x * d, tiles_y * d, B * nH), block 512 = 128 pixels x 4 lanes
+template <int K>
+__global__ __launch_bounds__(512) void na2d_fwd_tiled_kernel(Na2d p) {
+    constexpr int RB = 2 * K - 1, NS = K / 2, HH = NA_TH + K - 1, HW = NA_TW + K - 1;
+    __shared__ __attribute__((aligned(16))) bf16 ks[HH * HW * 32];
+    __shared__ __attribute__((aligned(16))) bf16 vs[HH * HW * 32];
+    __shared__ float rpb[RB * RB];
+    const int h = blockIdx.z % p.nH, b = blockIdx.z / p.nH;
+    const int ry = blockIdx.y % p.d, rx = blockIdx.x % p.d;
+    const int py0 = (blockIdx.y / p.d) * NA_TH, px0 = (blockIdx.x / p.d) * NA_TW;
+    const int Ly = (p.H - ry + p.d - 1) / p.d, Lx = (p.W - rx + p.d - 1) / p.d;
+    if (py0 >= Ly || px0 >= Lx) return;                    // (uniform: before any barrier)
+    const int C = p.nH * 32;
+    // halo = [hsy, hey) x [hsx, hex) in class positions: from the first pixel's window start to the last pixel's window end
+    const int hsy = min(max(py0 - NS, 0), Ly - K), hey = min(max(min(py0 + NA_TH, Ly) - 1 - NS, 0), Ly - K) + K;
+    const int hsx = min(max(px0 - NS, 0), Lx - K), hex = min(max(min(px0 + NA_TW, Lx) - 1 - NS, 0), Lx - K) + K;
+    const int hh = hey - hsy, hw = hex - hsx;
+    for (int i = threadIdx.x; i < RB * RB; i += 512) rpb[i] = p.rpb ? p.rpb[h * RB * RB + i] * LOG2E : 0.f;
+    for (int i = threadIdx.x; i < hh * hw * 4; i += 512) {
+        const int c = (i & 3) * 8, px = i >> 2;
+        const int yy = px / hw, xx = px - yy * hw;
+        const bf16* src = p.qkv + (((long)b * p.H + (hsy + yy) * p.d + ry) * p.W + (hsx + xx) * p.d + rx) * 3 * C + C + h * 32 + c;
+        *(bf16x8*)(ks + (yy * HW + xx) * 32 + c) = *(const bf16x8*)src;
+        *(bf16x8*)(vs + (yy * HW + xx) * 32 + c) = *(const bf16x8*)(src + C);
+    }
+    __syncthreads();
+    const int c8 = (threadIdx.x & 3) * 8;
+    const int ql = threadIdx.x >> 2;
+    const int pyr = py0 + ql / NA_TW, pxr = px0 + ql % NA_TW;
+    const bool valid = pyr < Ly && pxr < Lx;
+    const int py = min(pyr, Ly - 1), px = min(pxr, Lx - 1);
+    const int y = py * p.d + ry, x = px * p.d + rx;
+    const long pix = ((long)b * p.H + y) * p.W + x;
+    const bf16x8 q = *(const bf16x8*)(p.qkv + pix * 3 * C + h * 32 + c8);
+    const int sy = min(max(py - NS, 0), Ly - K), sx = min(max(px - NS, 0), Lx - K);
+    const int pby = sy - py + K - 1, pbx = sx - px + K - 1;
+    const bf16* kb = ks + ((sy - hsy) * HW + (sx - hsx)) * 32 + c8;
+    const bf16* vb = vs + ((sy - hsy) * HW + (sx - hsx)) * 32 + c8;
+    const float qs = p.scale * LOG2E;
+    float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < K; ++i) {
+        float s[K];
+        float mx = m;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bf16x8 kv = *(const bf16x8*)(kb + (i * HW + j) * 32);
+            s[j] = quad_sum(dot8_bf16(kv, q)) * qs + rpb[(pby + i) * RB + pbx + j];
+            mx = fmaxf(mx, s[j]);
+        }
+        const float corr = fast_exp2(m - mx);
+        l *= corr;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] *= corr;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bf16x8 vv = *(const bf16x8*)(vb + (i * HW + j) * 32);
+            const float pj = fast_exp2(s[j] - mx);
+            l += pj;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += pj * (float)vv[c];
+        }
+        m = mx;
+    }
+    if (!valid) return;
+    const float inv = 1.0f / l;
+    bf16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (bf16)(acc[c] * inv);
+    *(bf16x8*)(p.out + pix * C + h * 32 + c8) = o;
+    if (c8 == 0 && p.lse) p.lse[(((long)b * p.nH + h) * p.H + y) * p.W + x] = (m + __log2f(l)) * LN2;
+}
+
 // dq, drpb and delta = dout . out.  Same grid; drpb partial sums per block in LDS (one LDS atomic per wave and window slot
 // when the wave's 16 pixels share the bias entry -- always, away from the left / right border), then one global atomic per bin.
 template <int K>
@@ -163,8 +272,8 @@ __global__ __launch_bounds__(256) void na2d_bwd_q_kernel(Na2d p) {
             for (int c = 0; c < 8; ++c) dq[c] += ds * (float)kv[c];
             if (p.drpb) {
                 if (uniform) {
-                    ds += __shfl_xor(ds, 4); ds += __shfl_xor(ds, 8); ds += __shfl_xor(ds, 16); ds += __shfl_xor(ds, 32);
-                    if (lane == 0) atomicAdd(&dbin[(wy.pb0 + i) * RB + pb_first + j], ds);
+                    ds = pixels_sum_lane63(ds);
+                    if (lane == 63) atomicAdd(&dbin[(wy.pb0 + i) * RB + pb_first + j], ds);
                 } else if (valid && c8 == 0) {
                     atomicAdd(&dbin[bin], ds);
                 }
@@ -235,6 +344,170 @@ __global__ __launch_bounds__(256) void na2d_bwd_kv_kernel(Na2d p) {
     *(bf16x8*)(p.dqkv + pix * 3 * C + 2 * C + h * 32 + c8) = ov;
 }
 
+// ---- LDS-tiled backward, per query: dq, drpb, delta (same tile / halo as the forward) ----
+template <int K>
+__global__ __launch_bounds__(512) void na2d_bwd_q_tiled_kernel(Na2d p) {
+    constexpr int RB = 2 * K - 1, NS = K / 2, HH = NA_TH + K - 1, HW = NA_TW + K - 1;
+    __shared__ __attribute__((aligned(16))) bf16 ks[HH * HW * 32];
+    __shared__ __attribute__((aligned(16))) bf16 vs[HH * HW * 32];
+    __shared__ float rpb[RB * RB];
+    __shared__ float dbin[RB * RB];
+    const int h = blockIdx.z % p.nH, b = blockIdx.z / p.nH;
+    const int ry = blockIdx.y % p.d, rx = blockIdx.x % p.d;
+    const int py0 = (blockIdx.y / p.d) * NA_TH, px0 = (blockIdx.x / p.d) * NA_TW;
+    const int Ly = (p.H - ry + p.d - 1) / p.d, Lx = (p.W - rx + p.d - 1) / p.d;
+    if (py0 >= Ly || px0 >= Lx) return;
+    const int C = p.nH * 32;
+    const int hsy = min(max(py0 - NS, 0), Ly - K), hey = min(max(min(py0 + NA_TH, Ly) - 1 - NS, 0), Ly - K) + K;
+    const int hsx = min(max(px0 - NS, 0), Lx - K), hex = min(max(min(px0 + NA_TW, Lx) - 1 - NS, 0), Lx - K) + K;
+    const int hh = hey - hsy, hw = hex - hsx;
+    for (int i = threadIdx.x; i < RB * RB; i += 512) { rpb[i] = p.rpb ? p.rpb[h * RB * RB + i] * LOG2E : 0.f; dbin[i] = 0.f; }
+    for (int i = threadIdx.x; i < hh * hw * 4; i += 512) {
+        const int c = (i & 3) * 8, px = i >> 2;
+        const int yy = px / hw, xx = px - yy * hw;
+        const bf16* src = p.qkv + (((long)b * p.H + (hsy + yy) * p.d + ry) * p.W + (hsx + xx) * p.d + rx) * 3 * C + C + h * 32 + c;
+        *(bf16x8*)(ks + (yy * HW + xx) * 32 + c) = *(const bf16x8*)src;
+        *(bf16x8*)(vs + (yy * HW + xx) * 32 + c) = *(const bf16x8*)(src + C);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int c8 = (threadIdx.x & 3) * 8;
+    const int ql = threadIdx.x >> 2;
+    const int pyr = py0 + ql / NA_TW, pxr = px0 + ql % NA_TW;
+    const bool valid = pyr < Ly && pxr < Lx;
+    const int py = min(pyr, Ly - 1), px = min(pxr, Lx - 1);
+    const int y = py * p.d + ry, x = px * p.d + rx;
+    const long pix = ((long)b * p.H + y) * p.W + x;
+    const bf16x8 q = *(const bf16x8*)(p.qkv + pix * 3 * C + h * 32 + c8);
+    const bf16x8 g = *(const bf16x8*)(p.dout + pix * C + h * 32 + c8);
+    float delta;
+    {
+        const bf16x8 ov = *(const bf16x8*)(p.out + pix * C + h * 32 + c8);
+        float dl = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dl += (float)g[c] * (float)ov[c];
+        delta = quad_sum(dl);
+    }
+    const long si = (((long)b * p.nH + h) * p.H + y) * p.W + x;
+    const float lse2 = p.lse[si] * LOG2E;
+    if (valid && c8 == 0) p.delta[si] = delta;
+    const int sy = min(max(py - NS, 0), Ly - K), sx = min(max(px - NS, 0), Lx - K);
+    const int pby = sy - py + K - 1, pbx = sx - px + K - 1;
+    const bf16* kb = ks + ((sy - hsy) * HW + (sx - hsx)) * 32 + c8;
+    const bf16* vb = vs + ((sy - hsy) * HW + (sx - hsx)) * 32 + c8;
+    const float qs = p.scale * LOG2E;
+    // a wave = the 16 pixels of one tile row: they share the bias row, and the bias column too unless the row touches a border
+    const int pb_first = __shfl(pbx, 0);
+    const bool uniform = __all(pbx == pb_first || !valid);
+    float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < K; ++i) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bf16x8 kv = *(const bf16x8*)(kb + (i * HW + j) * 32);
+            const bf16x8 vv = *(const bf16x8*)(vb + (i * HW + j) * 32);
+            const int bin = (pby + i) * RB + pbx + j;
+            const float s = quad_sum(dot8_bf16(kv, q)) * qs + rpb[bin];
+            const float pr = fast_exp2(s - lse2);
+            const float dp = quad_sum(dot8_bf16(vv, g));
+            float ds = valid ? pr * (dp - delta) : 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dq[c] += ds * (float)kv[c];
+            if (p.drpb) {
+                if (uniform) {
+                    ds = pixels_sum_lane63(ds);
+                    if (lane == 63) atomicAdd(&dbin[(pby + i) * RB + pb_first + j], ds);
+                } else if (valid && c8 == 0) {
+                    atomicAdd(&dbin[bin], ds);
+                }
+            }
+        }
+    }
+    if (valid) {
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (bf16)(dq[c] * p.scale);
+        *(bf16x8*)(p.dqkv + pix * 3 * C + h * 32 + c8) = o;
+    }
+    if (p.drpb) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < RB * RB; i += 512)
+            if (dbin[i] != 0.f) atomicAdd(p.drpb + h * RB * RB + i, dbin[i]);
+    }
+}
+
+// ---- LDS-tiled backward, per key: dk, dv.  Tile of 8 x 16 KEY class positions; the q and dout rows (and lse, delta) of every
+// query whose window can contain one of them -- NATTEN's inverse neighbourhood: T + K - 1 positions per axis in the interior,
+// T + K + K/2 - 1 next to a border, the whole class when it is shorter than T + 2K - 1 -- are staged in LDS (58 KB at K = 7: two
+// workgroups per CU).  Used for K <= 7; larger kernels use the direct form. ----
+template <int K>
+__global__ __launch_bounds__(512) void na2d_bwd_kv_tiled_kernel(Na2d p) {
+    constexpr int RB = 2 * K - 1, NS = K / 2;
+    const int HW = p.hw_max, HP = p.hh_max * p.hw_max;       // halo row stride / positions (launch-wide maxima, see the launcher)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    bf16* qs_ = (bf16*)dyn;                                  // [HP][32]
+    bf16* gs = qs_ + HP * 32;                                // [HP][32]
+    float* ls = (float*)(gs + HP * 32);                      // [HP] lse (log2 domain)
+    float* dl = ls + HP;                                     // [HP] delta
+    float* rpb = dl + HP;                                    // [RB * RB]
+    const int h = blockIdx.z % p.nH, b = blockIdx.z / p.nH;
+    const int ry = blockIdx.y % p.d, rx = blockIdx.x % p.d;
+    const int py0 = (blockIdx.y / p.d) * NA_TH, px0 = (blockIdx.x / p.d) * NA_TW;
+    const int Ly = (p.H - ry + p.d - 1) / p.d, Lx = (p.W - rx + p.d - 1) / p.d;
+    if (py0 >= Ly || px0 >= Lx) return;
+    const int C = p.nH * 32;
+    const int pyl = min(py0 + NA_TH, Ly) - 1, pxl = min(px0 + NA_TW, Lx) - 1;          // last key of the tile
+    const int hsy = py0 < K ? 0 : py0 - NS, hey = pyl >= Ly - K ? Ly : pyl + NS + 1;
+    const int hsx = px0 < K ? 0 : px0 - NS, hex = pxl >= Lx - K ? Lx : pxl + NS + 1;
+    const int hh = hey - hsy, hw = hex - hsx;
+    for (int i = threadIdx.x; i < RB * RB; i += 512) rpb[i] = p.rpb ? p.rpb[h * RB * RB + i] * LOG2E : 0.f;
+    for (int i = threadIdx.x; i < hh * hw * 4; i += 512) {
+        const int c = (i & 3) * 8, px = i >> 2;
+        const int yy = px / hw, xx = px - yy * hw;
+        const int gy = (hsy + yy) * p.d + ry, gx = (hsx + xx) * p.d + rx;
+        const long gp = ((long)b * p.H + gy) * p.W + gx;
+        *(bf16x8*)(qs_ + (yy * HW + xx) * 32 + c) = *(const bf16x8*)(p.qkv + gp * 3 * C + h * 32 + c);
+        *(bf16x8*)(gs + (yy * HW + xx) * 32 + c) = *(const bf16x8*)(p.dout + gp * C + h * 32 + c);
+        if (c == 0) {
+            const long si = (((long)b * p.nH + h) * p.H + gy) * p.W + gx;
+            ls[yy * HW + xx] = p.lse[si] * LOG2E;
+            dl[yy * HW + xx] = p.delta[si];
+        }
+    }
+    __syncthreads();
+    const int c8 = (threadIdx.x & 3) * 8;
+    const int ql = threadIdx.x >> 2;
+    const int py = py0 + ql / NA_TW, px = px0 + ql % NA_TW;
+    if (py >= Ly || px >= Lx) return;                        // whole quads leave together
+    const int y = py * p.d + ry, x = px * p.d + rx;
+    const long pix = ((long)b * p.H + y) * p.W + x;
+    const bf16x8 kv = *(const bf16x8*)(p.qkv + pix * 3 * C + C + h * 32 + c8);
+    const bf16x8 vv = *(const bf16x8*)(p.qkv + pix * 3 * C + 2 * C + h * 32 + c8);
+    const int qy0 = py < K ? 0 : py - NS, qy1 = py >= Ly - K ? Ly : py + NS + 1;
+    const int qx0 = px < K ? 0 : px - NS, qx1 = px >= Lx - K ? Lx : px + NS + 1;
+    const float qsc = p.scale * LOG2E;
+    float dk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int qpy = qy0; qpy < qy1; ++qpy) {
+        const int by = py - qpy + K - 1;
+        const int rowl = (qpy - hsy) * HW - hsx;
+        for (int qpx = qx0; qpx < qx1; ++qpx) {
+            const int li = rowl + qpx;
+            const bf16x8 qv = *(const bf16x8*)(qs_ + li * 32 + c8);
+            const bf16x8 gv = *(const bf16x8*)(gs + li * 32 + c8);
+            const float s = quad_sum(dot8_bf16(qv, kv)) * qsc + rpb[by * RB + px - qpx + K - 1];
+            const float pr = fast_exp2(s - ls[li]);
+            const float dp = quad_sum(dot8_bf16(gv, vv));
+            const float ds = pr * (dp - dl[li]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { dv[c] += pr * (float)gv[c]; dk[c] += ds * (float)qv[c]; }
+        }
+    }
+    bf16x8 ok, ov;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { ok[c] = (bf16)(dk[c] * p.scale); ov[c] = (bf16)dv[c]; }
+    *(bf16x8*)(p.dqkv + pix * 3 * C + C + h * 32 + c8) = ok;
+    *(bf16x8*)(p.dqkv + pix * 3 * C + 2 * C + h * 32 + c8) = ov;
+}
+
 static int na2d_check(const Na2d& p, int K) {
     UENC_CHECK_ARG(p.B > 0 && p.H > 0 && p.W > 0 && p.nH > 0 && p.d >= 1);
     UENC_CHECK_ARG(K >= 3 && K <= 13 && (K & 1));
@@ -253,6 +526,16 @@ static int na2d_check(const Na2d& p, int K) {
         default: hipLaunchKernelGGL(KERNEL<13>, grid, dim3(256), 0, stream, p); break;                          \
     }
 
+#define NA2D_DISPATCH512(KERNEL)                                                                                \
+switch (K) {                                                                                            \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(512), 0, stream, p); break;                        \
+    case 5: hipLaunchKernelGGL(KERNEL<5>, grid, dim3(512), 0, stream, p); break;                        \
+    case 7: hipLaunchKernelGGL(KERNEL<7>, grid, dim3(512), 0, stream, p); break;                        \
+    case 9: hipLaunchKernelGGL(KERNEL<9>, grid, dim3(512), 0, stream, p); break;                        \
+    case 11: hipLaunchKernelGGL(KERNEL<11>, grid, dim3(512), 0, stream, p); break;                      \
+    default: hipLaunchKernelGGL(KERNEL<13>, grid, dim3(512), 0, stream, p); break;                      \
+}
+
 extern "C" int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float* lse, int B, int H, int W, int nH, int K, int dilation,
                              float scale, hipStream_t stream) {
     UENC_CHECK_ARG(qkv && out);
@@ -262,8 +545,16 @@ extern "C" int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float
     p.B = B; p.H = H; p.W = W; p.nH = nH; p.d = dilation; p.scale = scale;
     const int rc = na2d_check(p, K);
     if (rc != UENC_OK) return rc;
-    const dim3 grid((W + 63) / 64, H, B * nH);
-    NA2D_DISPATCH(na2d_fwd_kernel);
+    const char* ev = getenv("UENC_NA2D_VARIANT");
+    if (ev && (atoi(ev) & 1)) {                                // A/B: the direct (L1-gather) kernel
+        const dim3 grid((W + 63) / 64, H, B * nH);
+        NA2D_DISPATCH(na2d_fwd_kernel);
+    } else {
+        const int Lx = (W + dilation - 1) / dilation, Ly = (H + dilation - 1) / dilation;      // the longest residue class
+        UENC_CHECK_ARG((long)((Ly + NA_TH - 1) / NA_TH) * dilation <= 65535);
+        const dim3 grid(((Lx + NA_TW - 1) / NA_TW) * dilation, ((Ly + NA_TH - 1) / NA_TH) * dilation, B * nH);
+        NA2D_DISPATCH512(na2d_fwd_tiled_kernel);
+    }
     UENC_LAUNCH_RET();
 }
 
@@ -279,8 +570,36 @@ extern "C" int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out,
     p.B = B; p.H = H; p.W = W; p.nH = nH; p.d = dilation; p.scale = scale;
     const int rc = na2d_check(p, K);
     if (rc != UENC_OK) return rc;
-    const dim3 grid((W + 63) / 64, H, B * nH);
-    NA2D_DISPATCH(na2d_bwd_q_kernel);
-    NA2D_DISPATCH(na2d_bwd_kv_kernel);
+    const char* ev = getenv("UENC_NA2D_VARIANT");
+    const bool direct = ev && (atoi(ev) & 1);                 // A/B: the direct (L1-gather) kernels
+    const int Lx = (W + dilation - 1) / dilation, Ly = (H + dilation - 1) / dilation;
+    const dim3 tgrid(((Lx + NA_TW - 1) / NA_TW) * dilation, ((Ly + NA_TH - 1) / NA_TH) * dilation, B * nH);
+    UENC_CHECK_ARG(tgrid.y <= 65535);
+    {
+        dim3 grid = tgrid;
+        if (direct) { grid = dim3((W + 63) / 64, H, B * nH); NA2D_DISPATCH(na2d_bwd_q_kernel); }
+        else { NA2D_DISPATCH512(na2d_bwd_q_tiled_kernel); }
+    }
+    if (direct || K > 7) {
+        const dim3 grid((W + 63) / 64, H, B * nH);
+        NA2D_DISPATCH(na2d_bwd_kv_kernel);
+    } else {
+        // halo extent per axis: T + K + K/2 - 1 beside one border; a class shorter than T + 2K - 1 can touch both: all of it
+        const int NSh = K / 2;
+        p.hh_max = Ly >= NA_TH + 2 * K - 1 ? NA_TH + K + NSh - 1 : (Ly < NA_TH + 2 * K - 2 ? Ly : NA_TH + 2 * K - 2);
+        p.hw_max = Lx >= NA_TW + 2 * K - 1 ? NA_TW + K + NSh - 1 : (Lx < NA_TW + 2 * K - 2 ? Lx : NA_TW + 2 * K - 2);
+        const int SHM = p.hh_max * p.hw_max * (2 * 64 + 8) + (2 * K - 1) * (2 * K - 1) * 4;
+#define NA2D_KV_TILED(KK)                                                                                                           \
+        {                                                                                                                            \
+            static int attr = 0;                                                                                                     \
+            if (attr < SHM) {                                                                                                        \
+                hipError_t e = hipFuncSetAttribute((const void*)na2d_bwd_kv_tiled_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM); \
+                if (e != hipSuccess) return (int)e;                                                                                  \
+                attr = SHM;                                                                                                          \
+            }                                                                                                                        \
+            hipLaunchKernelGGL(na2d_bwd_kv_tiled_kernel<KK>, tgrid, dim3(512), SHM, stream, p);                                      \
+        }
+        if (K == 3) NA2D_KV_TILED(3) else if (K == 5) NA2D_KV_TILED(5) else NA2D_KV_TILED(7)
+    }
     UENC_LAUNCH_RET();
 }
