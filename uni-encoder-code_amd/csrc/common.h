@@ -41,6 +41,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Sums on DPP (VALU cross-lane operands) instead of __shfl_xor, which compiles to ds_bpermute_b32 and takes the LDS crossbar:
+// matters in kernels whose LDS pipe is already busy.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over aligned groups of 8 lanes, result in every lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float group8_sum(float v) {
+    v = dpp_add_f32<0xB1>(v);
+    v = dpp_add_f32<0x4E>(v);
+    return dpp_add_f32<0x141>(v);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -349,12 +349,7 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
                 g_w = (float)Wl * w * (-t.hh * d1 + t.hh * d2 - t.lh * d3 + t.lh * d4);
                 g_h = (float)Hl * w * (-t.hw * d1 - t.lw * d2 + t.hw * d3 + t.lw * d4);
             }
-#pragma unroll
-            for (int o = 4; o > 0; o >>= 1) {
-                g_w += __shfl_xor(g_w, o);
-                g_h += __shfl_xor(g_h, o);
-                g_a += __shfl_xor(g_a, o);
-            }
+            g_w = group8_sum(g_w); g_h = group8_sum(g_h); g_a = group8_sum(g_a);
             // every lane of the group now holds the sums: lane (s & 7) keeps sample s, so that the group's L*P results leave as
             // contiguous 64-byte rows (8 lanes x float2) instead of one 8-byte store per sample from lane 0
             if (j8 == (s & 7)) {
