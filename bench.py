@@ -232,7 +232,7 @@ def main():
                          "families": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,
                                           "ms_per_step": round(v[0] / max(args.steps, 1), 2), "launches_per_step": v[2] // max(args.steps, 1)}
                                       for k, v in fams.items()}},
-            "loss": round(float(loss), 5),
+            "loss": round(float(loss.detach()), 5),
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()

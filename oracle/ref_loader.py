@@ -184,3 +184,48 @@ def load():
     ns.swin, ns.msda_func, ns.msda_mod, ns.pe, ns.transformer, ns.pixdec, ns.dec = swin, func, mods, pe, tr, pix, dec
     ns.ShapeSpec = _ShapeSpec
     return ns
+
+
+def load_meta_arch():
+    """The reference's `OneFormer` class object (model/oneformer_model.py), for its pure post-processing methods
+    (`semantic_inference`, `panoptic_inference`, `instance_inference`: oneformer_model.py:367-489), called unbound on a
+    SimpleNamespace `self`.  The file's module-level imports need more of detectron2 (stand-ins below, documented semantics)
+    and three of the reference's own modules that only the depth / pose / motion branch uses; those are satisfied by empty
+    name holders so that their files (and their further dependencies) are never executed."""
+    assert available(), "reference tree not present"
+    ns = load()
+
+    def sem_seg_postprocess(result, img_size, output_height, output_width):
+        # detectron2.modeling.postprocessing.sem_seg_postprocess: crop the padding away, resize to the requested resolution
+        result = result[:, : img_size[0], : img_size[1]].expand(1, -1, -1, -1)
+        return F.interpolate(result, size=(output_height, output_width), mode="bilinear", align_corners=False)[0]
+
+    class _Instances:
+        def __init__(self, image_size):
+            self.image_size = image_size
+
+    class _Boxes:
+        def __init__(self, tensor):
+            self.tensor = tensor
+
+    d2m = sys.modules["detectron2.modeling"]
+    d2m.META_ARCH_REGISTRY = _Registry("META_ARCH")
+    d2m.build_backbone = d2m.build_sem_seg_head = None
+    _mod("detectron2.data", MetadataCatalog=None)
+    _mod("detectron2.modeling.backbone", Backbone=nn.Module)
+    _mod("detectron2.modeling.postprocessing", sem_seg_postprocess=sem_seg_postprocess)
+    _mod("detectron2.structures", Boxes=_Boxes, ImageList=None, Instances=_Instances, BitMasks=None)
+    _mod("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
+    base = os.path.join(REF_ROOT, "model")
+    for name, sub in [("model.modeling.motion_decoder", "modeling/motion_decoder"), ("model.modeling.pose_decoder", "modeling/pose_decoder"),
+                      ("model.data", "data")]:
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(base, sub)]
+        sys.modules[name] = m
+    _mod("model.modeling.motion_decoder.dynamo_motion_decoder_mod", MotionDecoderV2=None)
+    _mod("model.modeling.pose_decoder.resnet_like_pose_decoder", ResNetLike=None)
+    _mod("model.modeling.monodepth_loss", transformation_from_parameters=None)
+    _mod("model.data.tokenizer", SimpleTokenizer=None, Tokenize=None)
+    m = _load("model.oneformer_model", "oneformer_model.py")
+    ns.OneFormer = m.OneFormer
+    return ns
