@@ -226,6 +226,24 @@ int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float* lse, int 
 int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out, const void* dout, const float* lse, void* dqkv, float* drpb,
                   float* delta_ws, int B, int H, int W, int nH, int K, int dilation, float scale, void* stream);
 
+/* ---- segmentation post-processing fused with the mask upsample (inference) ---------------------------------------
+ * The reference upsamples the (Q, h, w) mask logits to the padded input size (model/oneformer_model.py:255-263), crops the
+ * padding (detectron2 sem_seg_postprocess, :277-279) and then runs semantic_inference (:367-371) / panoptic_inference
+ * (:373-434) on the 1.25 GB-per-image result.  These entry points interpolate on the fly from the low-resolution logits
+ * (bilinear, align_corners = False to (Hp, Wp); output extent (Ho, Wo) <= (Hp, Wp) = the crop); all tensors fp32 / int32,
+ * one image per call.
+ *   semantic:        sem (C, Ho, Wo) = sum_q class_prob[q, c] * sigmoid(up(mask_logits[q])); class_prob (Q, Cp), Cp % 32 == 0
+ *   panoptic_stats:  ids (Ho, Wo) = argmax_q score[q] * sigmoid(up(m_q)) over queries with score > 0 (first maximum wins);
+ *                    counts (3, Q), zeroed by the caller: |ids == q|, |sigmoid(up(m_q)) >= 0.5|, |both| -- what the reference
+ *                    reads back with three .item() syncs per query (:399-408)
+ *   panoptic_label:  seg (Ho, Wo) = segid[ids] where that query's sigmoid >= 0.5, else 0 (:420-425); segid (Q), 0 = dropped */
+int uenc_postproc_semantic(const float* mask_logits, const float* class_prob, float* sem, int Q, int C, int Cp, int hl, int wl,
+                           int Hp, int Wp, int Ho, int Wo, void* stream);
+int uenc_postproc_panoptic_stats(const float* mask_logits, const float* score, int* ids, int* counts, int Q, int hl, int wl, int Hp,
+                                 int Wp, int Ho, int Wo, void* stream);
+int uenc_postproc_panoptic_label(const float* mask_logits, const int* ids, const int* segid, int* seg, int Q, int hl, int wl, int Hp,
+                                 int Wp, int Ho, int Wo, void* stream);
+
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */
 int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile), 1 gemm_tn*, 4 gemm_nt256 */, double* ms_total, double* flops_total, long* launches);

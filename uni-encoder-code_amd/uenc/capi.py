@@ -57,6 +57,9 @@ _SIGNATURES = {
     "uenc_window_attn_np": [c_i],
     "uenc_relpos_expand": [c_p, c_p, c_p, c_i, c_i, c_p],
     "uenc_window_attn_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_postproc_semantic": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_postproc_panoptic_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_postproc_panoptic_label": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_na2d_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_na2d_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_window_attn_bwd_ws_floats": [c_i, c_i, c_i, c_i, c_i],

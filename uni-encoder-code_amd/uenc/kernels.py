@@ -161,6 +161,42 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
     return dx
 
 
+def postproc_semantic(mask_logits: torch.Tensor, class_prob: torch.Tensor, padded_size, out_size) -> torch.Tensor:
+    """mask_logits (Q, h, w) fp32, class_prob (Q, C) fp32 -> (C, Ho, Wo) fp32 = sum_q p[q, c] * sigmoid(upsample(m_q)), upsampled
+    to `padded_size` and cropped to `out_size` without materialising the (Q, H, W) masks."""
+    Q, hl, wl = mask_logits.shape
+    C = class_prob.shape[1]
+    assert mask_logits.dtype == torch.float32 and mask_logits.is_contiguous() and class_prob.shape[0] == Q
+    Cp = -(-C // 32) * 32
+    P = torch.zeros((Q, Cp), dtype=torch.float32, device=mask_logits.device)
+    P[:, :C] = class_prob
+    sem = torch.empty((C, out_size[0], out_size[1]), dtype=torch.float32, device=mask_logits.device)
+    check(lib.uenc_postproc_semantic(mask_logits.data_ptr(), P.data_ptr(), sem.data_ptr(), Q, C, Cp, hl, wl, padded_size[0], padded_size[1],
+                                     out_size[0], out_size[1], stream_ptr()), "postproc_semantic")
+    return sem
+
+
+def postproc_panoptic_stats(mask_logits: torch.Tensor, score: torch.Tensor, padded_size, out_size):
+    """-> ids (Ho, Wo) int32 (argmax over queries with score > 0 of score * sigmoid(upsampled mask)), counts (3, Q) int32:
+    pixels won, pixels with sigmoid >= 0.5, pixels with both."""
+    Q, hl, wl = mask_logits.shape
+    assert mask_logits.dtype == torch.float32 and mask_logits.is_contiguous() and score.dtype == torch.float32 and score.numel() == Q
+    ids = torch.empty(tuple(out_size), dtype=torch.int32, device=mask_logits.device)
+    counts = torch.zeros((3, Q), dtype=torch.int32, device=mask_logits.device)
+    check(lib.uenc_postproc_panoptic_stats(mask_logits.data_ptr(), score.contiguous().data_ptr(), ids.data_ptr(), counts.data_ptr(), Q, hl, wl,
+                                           padded_size[0], padded_size[1], out_size[0], out_size[1], stream_ptr()), "postproc_panoptic_stats")
+    return ids, counts
+
+
+def postproc_panoptic_label(mask_logits: torch.Tensor, ids: torch.Tensor, segid: torch.Tensor, padded_size) -> torch.Tensor:
+    Q, hl, wl = mask_logits.shape
+    assert ids.dtype == torch.int32 and segid.dtype == torch.int32 and segid.numel() == Q and ids.is_contiguous()
+    seg = torch.empty_like(ids)
+    check(lib.uenc_postproc_panoptic_label(mask_logits.data_ptr(), ids.data_ptr(), segid.contiguous().data_ptr(), seg.data_ptr(), Q, hl, wl,
+                                           padded_size[0], padded_size[1], ids.shape[0], ids.shape[1], stream_ptr()), "postproc_panoptic_label")
+    return seg
+
+
 def na2d_fwd(qkv: torch.Tensor, rpb: Optional[torch.Tensor], nH: int, ks: int, dilation: int, scale: float, need_lse: bool = True):
     """Neighbourhood attention on qkv (B, H, W, 3C) bf16 (C = nH * 32) -> out (B, H, W, C) bf16, lse (B, nH, H, W) fp32."""
     B, H, W, C3 = qkv.shape

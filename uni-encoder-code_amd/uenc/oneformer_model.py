@@ -43,6 +43,9 @@ class OneFormer(nn.Module):
         self.task_tokenizer = Tokenize(max_seq_len=task_seq_len)
         self.is_demo = is_demo
         self._task_cache = {}
+        # contiguous ids of the 'thing' classes (reference: MetadataCatalog.get(cfg.DATASETS.TRAIN[0]).thing_dataset_id_to_contiguous_id,
+        # oneformer_model.py:124, 405); Cityscapes: classes 11..18.  Settable by the driver that knows the dataset.
+        self.thing_ids = tuple(range(11, 19))
 
     @classmethod
     def from_config(cls, cfg):
@@ -102,22 +105,101 @@ class OneFormer(nn.Module):
             raise NotImplementedError("the 'sequence' (depth / pose / motion) branch is out of the hot-path scope, SURVEY.md §8f")
         outputs, images = self.forward_features(batched_inputs)
         mask_cls_results = outputs["pred_logits"]
-        mask_pred_results = self.upsample_masks(outputs["pred_masks"], images.tensor.shape[-2:])
-        results = []
+        padded = tuple(images.tensor.shape[-2:])
         seg = [x for x in batched_inputs if x["type"] == "segmentation"]
-        for mask_cls, mask_pred, inp, image_size in zip(mask_cls_results, mask_pred_results, seg, images.image_sizes):
+        if self.instance_on:
+            raise NotImplementedError("instance_inference (oneformer_model.py:436-489) is not built: SURVEY.md §8f, DESIGN.md §8")
+        # Inference without gradients: the post-processing kernels interpolate the low-resolution mask logits on the fly, the
+        # (Q, H, W) upsampled masks (1.25 GB per 1024 x 2048 image) are never written (csrc/postproc.hip).  With gradients enabled,
+        # or when the requested output resolution differs from the image size (a second resize), the reference's sequence of
+        # separate passes runs: upsample (:255-263), crop + resize (sem_seg_postprocess), inference.
+        fused_ok = not (torch.is_grad_enabled() and outputs["pred_masks"].requires_grad)
+        mask_pred_results = None
+        results = []
+        for i, (mask_cls, inp, image_size) in enumerate(zip(mask_cls_results, seg, images.image_sizes)):
             height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
-            r = {"pred_logits": mask_cls, "pred_masks": mask_pred}
-            if self.semantic_on:
-                mp = mask_pred[:, : image_size[0], : image_size[1]]
+            r = {"pred_logits": mask_cls}
+            if fused_ok and (height, width) == tuple(image_size):
+                ml = outputs["pred_masks"][i].detach().float().contiguous()
+                if self.semantic_on:
+                    from . import kernels as K
+                    r["sem_seg"] = K.postproc_semantic(ml, F.softmax(mask_cls.detach().float(), dim=-1)[..., :-1], padded, tuple(image_size))
+                if self.panoptic_on:
+                    r["panoptic_seg"] = self.panoptic_inference_fused(mask_cls.detach().float(), ml, padded, tuple(image_size))
+            else:
+                if mask_pred_results is None:
+                    mask_pred_results = self.upsample_masks(outputs["pred_masks"], padded)
+                mp = mask_pred_results[i][:, : image_size[0], : image_size[1]]
                 if (height, width) != tuple(image_size):
                     mp = F.interpolate(mp[None], size=(height, width), mode="bilinear", align_corners=False)[0]
-                r["sem_seg"] = self.semantic_inference(mask_cls, mp)
+                r["pred_masks"] = mp
+                if self.semantic_on:
+                    r["sem_seg"] = self.semantic_inference(mask_cls, mp)
+                if self.panoptic_on:
+                    r["panoptic_seg"] = self.panoptic_inference(mask_cls, mp)
             results.append(r)
         return results
 
     @staticmethod
     def semantic_inference(mask_cls, mask_pred):
-        """reference oneformer_model.py semantic_inference: softmax over classes (drop no-object) x sigmoid masks."""
+        """reference oneformer_model.py:367-371: softmax over classes (drop no-object) x sigmoid masks."""
         mask_cls = F.softmax(mask_cls, dim=-1)[..., :-1]
         return torch.einsum("qc,qhw->chw", mask_cls, mask_pred.sigmoid())
+
+    def _segments(self, labels, scores, keep, area, orig, inter):
+        """The per-query decisions of panoptic_inference (:399-432) from host copies of the three pixel counts: returns the
+        segment id of every query (0 = dropped) and segments_info."""
+        segid, info, current, stuff = [0] * len(labels), [], 0, {}
+        for q in range(len(labels)):
+            if not keep[q]:
+                continue
+            c = int(labels[q])
+            isthing = c in self.thing_ids
+            if area[q] > 0 and orig[q] > 0 and inter[q] > 0:
+                if area[q] / orig[q] < self.overlap_threshold:
+                    continue
+                if not isthing:
+                    if c in stuff:
+                        segid[q] = stuff[c]
+                        continue
+                    stuff[c] = current + 1
+                current += 1
+                segid[q] = current
+                info.append({"id": current, "isthing": bool(isthing), "category_id": c})
+        return segid, info
+
+    def panoptic_inference_fused(self, mask_cls, mask_logits, padded_size, out_size):
+        """panoptic_inference (:373-434) on the LOW-resolution mask logits: argmax map and the three per-query pixel counts in one
+        kernel, ONE device-to-host copy (the reference: three `.item()` syncs per kept query), then the labelling kernel."""
+        from . import kernels as K
+        scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
+        keep = labels.ne(self.sem_seg_head.num_classes) & (scores > self.object_mask_threshold)
+        ids, counts = K.postproc_panoptic_stats(mask_logits, torch.where(keep, scores, torch.zeros_like(scores)), padded_size, out_size)
+        host = torch.cat([counts.flatten().float(), labels.float(), keep.float()]).cpu()          # the one synchronisation
+        Q = labels.numel()
+        area, orig, inter = (host[i * Q:(i + 1) * Q].long().tolist() for i in range(3))
+        segid, info = self._segments(host[3 * Q:4 * Q].long().tolist(), None, host[4 * Q:].bool().tolist(), area, orig, inter)
+        seg = K.postproc_panoptic_label(mask_logits, ids, torch.tensor(segid, dtype=torch.int32).to(ids.device), padded_size)
+        return seg, info
+
+    def panoptic_inference(self, mask_cls, mask_pred):
+        """reference oneformer_model.py:373-434 on materialised (Q, H, W) mask logits (the fallback path)."""
+        scores, labels = F.softmax(mask_cls, dim=-1).max(-1)
+        prob = mask_pred.sigmoid()
+        keep = labels.ne(self.sem_seg_head.num_classes) & (scores > self.object_mask_threshold)
+        h, w = prob.shape[-2:]
+        seg = torch.zeros((h, w), dtype=torch.int32, device=prob.device)
+        if int(keep.sum()) == 0:
+            return seg, []
+        ids = (torch.where(keep, scores, torch.zeros_like(scores)).view(-1, 1, 1) * prob).argmax(0)
+        over = prob >= 0.5
+        Q = labels.numel()
+        onehot = ids.flatten()
+        area = torch.bincount(onehot, minlength=Q)
+        orig = over.flatten(1).sum(1)
+        won = over.flatten(1).gather(0, onehot[None])[0]
+        inter = torch.bincount(onehot, weights=won.float(), minlength=Q).long()
+        segid, info = self._segments(labels.tolist(), None, keep.tolist(), area.tolist(), orig.tolist(), inter.tolist())
+        sid = torch.tensor(segid, dtype=torch.int32, device=prob.device)
+        seg = torch.where(won.view(h, w), sid[ids], torch.zeros_like(seg))
+        return seg, info
