@@ -87,3 +87,38 @@ def test_full_size_semantic_and_panoptic_consistency():
     seg2, info2 = o.panoptic_inference(cls, up)
     assert info == info2 and len(info) >= 3
     assert float((seg != seg2).float().mean()) <= 1e-5
+
+
+def test_oneformer_forward_inference_paths_agree():
+    """OneFormer.forward on a small model with semantic + panoptic inference on: the fused path (no_grad) against the
+    materialised path the same forward takes when gradients are enabled (separate upsample, crop, torch ops)."""
+    import model  # noqa: F401
+    from oracle import fill
+    from uenc.d2 import get_cfg, build_model
+    from uenc.config import add_common_config, add_swin_config, add_uni_encoder_config
+    cfg = get_cfg()
+    add_common_config(cfg); add_swin_config(cfg); add_uni_encoder_config(cfg)
+    cfg.merge_from_list([
+        "MODEL.META_ARCHITECTURE", "OneFormer", "MODEL.BACKBONE.NAME", "D2SwinTransformer", "MODEL.SWIN.EMBED_DIM", 64,
+        "MODEL.SWIN.DEPTHS", [2, 2, 2, 2], "MODEL.SWIN.NUM_HEADS", [2, 4, 8, 16], "MODEL.SEM_SEG_HEAD.NAME", "OneFormerHead",
+        "MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME", "MSDeformAttnPixelDecoder", "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 19,
+        "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.IN_FEATURES", ["res2", "res3", "res4", "res5"],
+        "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", 6, "MODEL.ONE_FORMER.TRANSFORMER_IN_FEATURE", "multi_scale_pixel_decoder",
+        "MODEL.ONE_FORMER.NUM_OBJECT_QUERIES", 150, "MODEL.ONE_FORMER.DEC_LAYERS", 10, "MODEL.IS_TRAIN", False,
+        "MODEL.TEST.SEMANTIC_ON", True, "MODEL.TEST.PANOPTIC_ON", True, "MODEL.TEST.INSTANCE_ON", False,
+        "MODEL.TEST.OBJECT_MASK_THRESHOLD", 0.05, "MODEL.TEST.OVERLAP_THRESHOLD", 0.05,
+        "MODEL.PIXEL_MEAN", [123.675, 116.280, 103.530], "MODEL.PIXEL_STD", [58.395, 57.120, 57.375], "MODEL.DEVICE", "cuda"])
+    m = build_model(cfg)
+    fill.fill_module(m, "")
+    m.eval()
+    g = torch.Generator().manual_seed(11)
+    # 90 x 120 is padded to 96 x 128 (size divisibility 32): the crop is part of both paths
+    batch = [{"left_image": torch.randint(0, 256, (3, 90, 120), generator=g).float(), "task": "The task is panoptic", "type": "segmentation"}]
+    with torch.no_grad():
+        fused = m(batch)[0]
+    slow = m(batch)[0]                      # gradients enabled -> the materialised path
+    assert "pred_masks" in slow and "pred_masks" not in fused
+    assert tuple(fused["sem_seg"].shape) == (19, 90, 120) and tuple(fused["panoptic_seg"][0].shape) == (90, 120)
+    assert float((fused["sem_seg"] - slow["sem_seg"].detach()).abs().max()) < 1e-4
+    assert fused["panoptic_seg"][1] == slow["panoptic_seg"][1]
+    assert float((fused["panoptic_seg"][0] != slow["panoptic_seg"][0]).float().mean()) <= 1e-3
