@@ -32,9 +32,16 @@ def main():
         mp = post(up, image, out[0], out[1])                                                              # :277-279 (before inference)
         sem = O.semantic_inference(fake, cls, mp)
         seg, info = O.panoptic_inference(fake, cls, mp)
+        fake.num_queries, fake.test_topk_per_image, fake.is_demo, fake.panoptic_on, fake.detection_on = Q, min(10, Q * C), False, i != 1, False
+        fake.device, fake.metadata.name = torch.device("cpu"), "cityscapes_fine_panoptic_val"
+        inst = O.instance_inference(fake, cls, mp, "The task is instance")                                 # :436-489
+        order = torch.argsort(inst.scores, descending=True)
         arrs.update({f"c{i}_cls": cls.numpy(), f"c{i}_masks": masks.numpy(),
                      f"c{i}_meta": np.array([Q, C, h, w, *padded, *image, *out], dtype=np.int64), f"c{i}_thr": np.array([thr, ovl]),
                      f"c{i}_things": np.array(things, dtype=np.int64), f"c{i}_mask_pred": mp.numpy(), f"c{i}_sem": sem.numpy(),
+                     f"c{i}_inst_scores": inst.scores[order].numpy(), f"c{i}_inst_classes": inst.pred_classes[order].numpy(),
+                     f"c{i}_inst_area": inst.pred_masks[order].flatten(1).sum(1).numpy(), f"c{i}_inst_topk": np.int64(fake.test_topk_per_image),
+                     f"c{i}_inst_panoptic_on": np.int64(int(fake.panoptic_on)),
                      f"c{i}_pan": seg.numpy(), f"c{i}_info": np.array([[d["id"], int(d["isthing"]), d["category_id"]] for d in info],
                                                                      dtype=np.int64).reshape(-1, 3)})
         print(f"case {i}: {len(info)} segments, ids {sorted(set(seg.flatten().tolist()))}")

@@ -1,7 +1,7 @@
 """CPU restatement (fp32, plain PyTorch) of the reference's segmentation post-processing.
 
 TEST INFRASTRUCTURE: only `tests/` imports it.  Parity status: PINNED -- `oracle/make_postproc_golden.py` calls the reference's
-own `OneFormer.semantic_inference` / `panoptic_inference` (model/oneformer_model.py:367-434, loaded through
+own `OneFormer.semantic_inference` / `panoptic_inference` / `instance_inference` (model/oneformer_model.py:367-489, loaded through
 `oracle/ref_loader.load_meta_arch`) and the documented `sem_seg_postprocess` on synthetic predictions and commits inputs +
 outputs as `tests/golden/postproc.npz`; `tests/test_postproc_cpu.py` checks this file against them (and live against the
 reference where /root/reference exists).  Citations are relative to /root/reference/model/oneformer_model.py.
@@ -62,6 +62,23 @@ def panoptic_inference(mask_cls: Tensor, mask_pred: Tensor, num_classes: int, ob
             seg[m] = current
             info.append({"id": current, "isthing": bool(isthing), "category_id": c})
     return seg, info
+
+
+def instance_inference(mask_cls: Tensor, mask_pred: Tensor, num_classes: int, topk: int, panoptic_on: bool, thing_ids: Sequence[int]):
+    """:436-489 (is_demo False, detection off, not ADE20K): -> dict(pred_masks (n, H, W) float {0, 1}, scores (n), pred_classes (n)),
+    in the order torch.topk(sorted=False) happened to return -- callers compare as sets."""
+    Q = mask_cls.shape[0]
+    scores = F.softmax(mask_cls, dim=-1)[:, :-1]
+    labels = torch.arange(num_classes).unsqueeze(0).repeat(Q, 1).flatten(0, 1)
+    s, idx = scores.flatten(0, 1).topk(topk, sorted=False)
+    lab = labels[idx]
+    mp = mask_pred[idx // num_classes]
+    if panoptic_on:
+        keep = torch.tensor([int(v) in thing_ids for v in lab], dtype=torch.bool)
+        s, lab, mp = s[keep], lab[keep], mp[keep]
+    pm = (mp > 0).float()
+    ms = (mp.sigmoid().flatten(1) * pm.flatten(1)).sum(1) / (pm.flatten(1).sum(1) + 1e-6)
+    return {"pred_masks": pm, "scores": s * ms, "pred_classes": lab}
 
 
 def synthetic_predictions(Q: int, C: int, h: int, w: int, seed: int = 0):

@@ -26,6 +26,11 @@ def test_oracle_matches_reference_fixtures():
         assert torch.equal(seg, g[f"c{i}_pan"].to(torch.int32))
         assert [[d["id"], int(d["isthing"]), d["category_id"]] for d in info] == g[f"c{i}_info"].tolist()
         assert len(info) >= 3                      # the fixtures exercise real segments (merge, overlap drop, no-object, low score)
+        inst = P.instance_inference(g[f"c{i}_cls"], mp, c["C"], int(g[f"c{i}_inst_topk"]), bool(int(g[f"c{i}_inst_panoptic_on"])), c["things"])
+        order = torch.argsort(inst["scores"], descending=True)          # topk(sorted=False): compare in score order
+        torch.testing.assert_close(inst["scores"][order], g[f"c{i}_inst_scores"], atol=1e-6, rtol=1e-5)
+        assert torch.equal(inst["pred_classes"][order], g[f"c{i}_inst_classes"])
+        torch.testing.assert_close(inst["pred_masks"][order].flatten(1).sum(1), g[f"c{i}_inst_area"])
 
 
 def test_oracle_matches_reference_live():

@@ -71,6 +71,25 @@ def test_panoptic_fallback_path_vs_reference_fixture():
         assert [[d["id"], int(d["isthing"]), d["category_id"]] for d in info] == g[f"c{i}_info"].tolist()
 
 
+def test_instance_inference_vs_reference_fixture():
+    """instance_inference on the low-resolution logits (selected queries upsampled only) and on materialised masks, against the
+    reference's Instances for the three fixture cases (detections compared in score order: topk(sorted=False) has no order)."""
+    from oracle import postproc_ref as P
+    for i, g, c in _cases(only_unresized=False):
+        o = _meta_arch(c)
+        o.test_topk_per_image, o.is_demo, o.panoptic_on = int(g[f"c{i}_inst_topk"]), False, bool(int(g[f"c{i}_inst_panoptic_on"]))
+        runs = [o.instance_inference(g[f"c{i}_cls"].cuda(), g[f"c{i}_mask_pred"].cuda(), "The task is instance")]
+        if c["out"] == c["image"]:
+            runs.append(o.instance_inference(g[f"c{i}_cls"].cuda(), g[f"c{i}_masks"].cuda(), "The task is instance", c["padded"], c["image"]))
+        for r in runs:
+            order = torch.argsort(r.scores, descending=True)
+            torch.testing.assert_close(r.scores[order].cpu(), g[f"c{i}_inst_scores"], atol=1e-5, rtol=1e-4)
+            assert torch.equal(r.pred_classes[order].cpu(), g[f"c{i}_inst_classes"])
+            area = r.pred_masks[order].flatten(1).sum(1).cpu()
+            assert float((area - g[f"c{i}_inst_area"]).abs().max()) <= 2.0          # pixels whose logit is within rounding of 0
+            assert tuple(r.pred_boxes.tensor.shape) == (len(order), 4) and r.image_size == tuple(r.pred_masks.shape[-2:])
+
+
 def test_full_size_semantic_and_panoptic_consistency():
     """1024 x 2048, Q = 150, C = 19: the fused kernels against the separate passes (upsample kernel + torch ops) on the same logits."""
     from oracle import postproc_ref as P
@@ -105,7 +124,7 @@ def test_oneformer_forward_inference_paths_agree():
         "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.IN_FEATURES", ["res2", "res3", "res4", "res5"],
         "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", 6, "MODEL.ONE_FORMER.TRANSFORMER_IN_FEATURE", "multi_scale_pixel_decoder",
         "MODEL.ONE_FORMER.NUM_OBJECT_QUERIES", 150, "MODEL.ONE_FORMER.DEC_LAYERS", 10, "MODEL.IS_TRAIN", False,
-        "MODEL.TEST.SEMANTIC_ON", True, "MODEL.TEST.PANOPTIC_ON", True, "MODEL.TEST.INSTANCE_ON", False,
+        "MODEL.TEST.SEMANTIC_ON", True, "MODEL.TEST.PANOPTIC_ON", True, "MODEL.TEST.INSTANCE_ON", True, "TEST.DETECTIONS_PER_IMAGE", 20,
         "MODEL.TEST.OBJECT_MASK_THRESHOLD", 0.05, "MODEL.TEST.OVERLAP_THRESHOLD", 0.05,
         "MODEL.PIXEL_MEAN", [123.675, 116.280, 103.530], "MODEL.PIXEL_STD", [58.395, 57.120, 57.375], "MODEL.DEVICE", "cuda"])
     m = build_model(cfg)
@@ -122,3 +141,8 @@ def test_oneformer_forward_inference_paths_agree():
     assert float((fused["sem_seg"] - slow["sem_seg"].detach()).abs().max()) < 1e-4
     assert fused["panoptic_seg"][1] == slow["panoptic_seg"][1]
     assert float((fused["panoptic_seg"][0] != slow["panoptic_seg"][0]).float().mean()) <= 1e-3
+    fi, si = fused["instances"], slow["instances"]
+    of, os_ = torch.argsort(fi.scores, descending=True), torch.argsort(si.scores, descending=True)
+    assert len(fi) == len(si) and torch.equal(fi.pred_classes[of], si.pred_classes[os_])
+    torch.testing.assert_close(fi.scores[of], si.scores[os_].detach(), atol=1e-5, rtol=1e-4)
+    assert fi.image_size == (90, 120) and tuple(fi.pred_masks.shape[-2:]) == (90, 120)

@@ -29,7 +29,7 @@ if HAVE_D2:  # pragma: no cover
     from detectron2.layers import Conv2d, ShapeSpec, get_norm
     from detectron2.modeling import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY, Backbone,
                                      build_backbone, build_model, build_sem_seg_head)
-    from detectron2.structures import ImageList
+    from detectron2.structures import Boxes, ImageList, Instances
     from detectron2.utils.registry import Registry
 else:
     class Registry:
@@ -222,6 +222,47 @@ else:
         def output_shape(self):
             return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
                     for name in self._out_features}
+
+    class Boxes:
+        """detectron2.structures.Boxes, the slice instance_inference uses: an (N, 4) tensor holder."""
+
+        def __init__(self, tensor: torch.Tensor):
+            self.tensor = tensor
+
+        def __len__(self):
+            return self.tensor.shape[0]
+
+    class Instances:
+        """detectron2.structures.Instances, the slice instance_inference uses: per-image fields set as attributes."""
+
+        def __init__(self, image_size: Tuple[int, int], **kwargs):
+            object.__setattr__(self, "_image_size", tuple(image_size))
+            object.__setattr__(self, "_fields", {})
+            for k, v in kwargs.items():
+                setattr(self, k, v)
+
+        @property
+        def image_size(self):
+            return self._image_size
+
+        def __setattr__(self, name, val):
+            self._fields[name] = val
+
+        def __getattr__(self, name):
+            if name == "_fields" or name not in self._fields:
+                raise AttributeError(f"Cannot find field '{name}' in the given Instances!")
+            return self._fields[name]
+
+        def has(self, name):
+            return name in self._fields
+
+        def get_fields(self):
+            return self._fields
+
+        def __len__(self):
+            for v in self._fields.values():
+                return len(v)
+            raise NotImplementedError("Empty Instances does not support __len__!")
 
     class ImageList:
         def __init__(self, tensor: torch.Tensor, image_sizes: List[Tuple[int, int]]):

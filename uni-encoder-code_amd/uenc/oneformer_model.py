@@ -16,7 +16,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import ops
-from .d2 import META_ARCH_REGISTRY, ImageList, build_backbone, build_sem_seg_head, configurable
+from .d2 import META_ARCH_REGISTRY, Boxes, ImageList, Instances, build_backbone, build_sem_seg_head, configurable
 from .modeling.transformer_decoder.oneformer_transformer_decoder import MLP
 from .tokenizer import Tokenize
 
@@ -107,8 +107,6 @@ class OneFormer(nn.Module):
         mask_cls_results = outputs["pred_logits"]
         padded = tuple(images.tensor.shape[-2:])
         seg = [x for x in batched_inputs if x["type"] == "segmentation"]
-        if self.instance_on:
-            raise NotImplementedError("instance_inference (oneformer_model.py:436-489) is not built: SURVEY.md §8f, DESIGN.md §8")
         # Inference without gradients: the post-processing kernels interpolate the low-resolution mask logits on the fly, the
         # (Q, H, W) upsampled masks (1.25 GB per 1024 x 2048 image) are never written (csrc/postproc.hip).  With gradients enabled,
         # or when the requested output resolution differs from the image size (a second resize), the reference's sequence of
@@ -126,6 +124,8 @@ class OneFormer(nn.Module):
                     r["sem_seg"] = K.postproc_semantic(ml, F.softmax(mask_cls.detach().float(), dim=-1)[..., :-1], padded, tuple(image_size))
                 if self.panoptic_on:
                     r["panoptic_seg"] = self.panoptic_inference_fused(mask_cls.detach().float(), ml, padded, tuple(image_size))
+                if self.instance_on:
+                    r["instances"] = self.instance_inference(mask_cls.detach().float(), ml, inp["task"], padded, tuple(image_size))
             else:
                 if mask_pred_results is None:
                     mask_pred_results = self.upsample_masks(outputs["pred_masks"], padded)
@@ -137,6 +137,8 @@ class OneFormer(nn.Module):
                     r["sem_seg"] = self.semantic_inference(mask_cls, mp)
                 if self.panoptic_on:
                     r["panoptic_seg"] = self.panoptic_inference(mask_cls, mp)
+                if self.instance_on:
+                    r["instances"] = self.instance_inference(mask_cls, mp, inp["task"])
             results.append(r)
         return results
 
@@ -181,6 +183,41 @@ class OneFormer(nn.Module):
         segid, info = self._segments(host[3 * Q:4 * Q].long().tolist(), None, host[4 * Q:].bool().tolist(), area, orig, inter)
         seg = K.postproc_panoptic_label(mask_logits, ids, torch.tensor(segid, dtype=torch.int32).to(ids.device), padded_size)
         return seg, info
+
+    def instance_inference(self, mask_cls, mask_pred, task_type, padded_size=None, image_size=None):
+        """reference oneformer_model.py:436-489 (detection off, not the ADE20K re-indexing).  mask_pred: the (Q, H, W) post-processed
+        mask logits, or -- with padded_size / image_size -- the LOW-resolution logits: then only the selected (<= top-k) queries are
+        upsampled and cropped (the reference upsamples all Q and gathers).  The class filter of the panoptic setting is one
+        torch.isin instead of a Python loop with a sync per detection."""
+        C = self.sem_seg_head.num_classes
+        scores = F.softmax(mask_cls, dim=-1)[:, :-1]
+        labels = torch.arange(C, device=mask_cls.device).unsqueeze(0).repeat(scores.shape[0], 1).flatten(0, 1)
+        scores_per_image, topk_indices = scores.flatten(0, 1).topk(self.test_topk_per_image, sorted=False)
+        labels_per_image = labels[topk_indices]
+        qidx = topk_indices // C
+        if self.is_demo:
+            keep = scores_per_image > self.object_mask_threshold
+            scores_per_image, labels_per_image, qidx = scores_per_image[keep], labels_per_image[keep], qidx[keep]
+        if self.panoptic_on:
+            keep = torch.isin(labels_per_image, torch.tensor(self.thing_ids, device=labels_per_image.device))
+            scores_per_image, labels_per_image, qidx = scores_per_image[keep], labels_per_image[keep], qidx[keep]
+        if padded_size is not None:
+            from . import kernels as K
+            sel = mask_pred[qidx].contiguous()
+            if sel.shape[0] > 0 and padded_size[1] % 4 == 0:
+                mask_pred = K.upsample_bilinear(sel[None], padded_size)[0][:, : image_size[0], : image_size[1]]
+            else:
+                mask_pred = F.interpolate(sel[None], size=tuple(padded_size), mode="bilinear", align_corners=False)[0][:, : image_size[0], : image_size[1]]
+        else:
+            mask_pred = mask_pred[qidx]
+        result = Instances(tuple(mask_pred.shape[-2:]))
+        result.pred_masks = (mask_pred > 0).float()
+        result.pred_boxes = Boxes(torch.zeros(mask_pred.size(0), 4))
+        flat = result.pred_masks.flatten(1)
+        mask_scores_per_image = (mask_pred.sigmoid().flatten(1) * flat).sum(1) / (flat.sum(1) + 1e-6)
+        result.scores = scores_per_image * mask_scores_per_image
+        result.pred_classes = labels_per_image
+        return result
 
     def panoptic_inference(self, mask_cls, mask_pred):
         """reference oneformer_model.py:373-434 on materialised (Q, H, W) mask logits (the fallback path)."""
