@@ -439,3 +439,48 @@ def test_swin_block_drop_path_training(ops):
     blk.eval()
     _check("eval", blk(x.detach()), ops.swin_block(x.detach(), H, W, ws, 2, nH, blk.attn.scale, blk._params()), 1e-6)
     ops.CACHE.invalidate()
+
+
+def test_deform_encoder_layer_training_dropout(ops):
+    """Training-mode dropout of the deformable encoder layer (dropout1 / 2 / 3, reference pixel_decoder/msdeformattn.py:111-142):
+    the layer run op by op with explicit keep-masks equals the oracle's layer arithmetic with the same masks, forward and backward;
+    eval mode keeps using the fused layer."""
+    import torch.nn.functional as F
+    from oracle import torch_ref as T, fill
+    from uenc.modeling.pixel_decoder.msdeformattn import MSDeformAttnTransformerEncoderLayer, MSDeformAttnTransformerEncoder
+    ops.CACHE.invalidate()
+    shapes = [(6, 8), (12, 16), (24, 32)]
+    S, B, C = sum(h * w for h, w in shapes), 2, 256
+    layer = MSDeformAttnTransformerEncoderLayer(C, 1024, 0.1, "relu", 3, 8, 4).cuda()
+    p = "sem_seg_head.pixel_decoder.transformer.encoder.layers.0"
+    fill.fill_module(layer, p + ".")
+    sd = {p + "." + k: v.detach().cpu().clone().requires_grad_() for k, v in layer.state_dict().items()}
+    src, pos = _r(B, S, C, seed=1), _r(B, S, C, seed=2, scale=0.5)
+    ss = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    ref = MSDeformAttnTransformerEncoder.get_reference_points(shapes, torch.ones(B, 3, 2, device="cuda"), "cuda").contiguous()
+    x = src.clone().requires_grad_()
+    layer.train()
+    y = layer(x, pos, ref, ss, lsi)
+    m1, m2, m3 = [m.cpu() for m in layer._masks]
+    assert 0.85 < float(m1.float().mean()) < 0.95 and m2.shape == (B, S, 1024)
+    dy = _r(B, S, C, seed=3)
+    y.backward(dy)
+    ops.flush_wgrads()
+    keep = 0.9
+    x2 = src.detach().cpu().requires_grad_()
+    a = T.ms_deform_attn(x2 + pos.cpu(), T.encoder_reference_points(shapes), x2, shapes, sd, p + ".self_attn", 8, 4)
+    h = T._ln(x2 + a * m1 / keep, sd, p + ".norm1")
+    t = F.relu(T._lin(h, sd, p + ".linear1")) * m2 / keep
+    y2 = T._ln(h + T._lin(t, sd, p + ".linear2") * m3 / keep, sd, p + ".norm2")
+    y2.backward(dy.cpu())
+    # gradients pass through bilinear sampling of a bf16 value map of white noise at bf16-rounded sampling offsets: 6e-2
+    _check("y", y.cpu(), y2, 2e-2); _check("dx", x.grad.cpu(), x2.grad, 6e-2)
+    assert float(F.cosine_similarity(x.grad.cpu().flatten(), x2.grad.flatten(), dim=0)) > 0.998
+    for name, q in layer.named_parameters():        # (sampling-offset gradients are heavily cancelling sums: direction and norm are checked)
+        want = sd[p + "." + name].grad
+        cos = float(F.cosine_similarity(q.grad.cpu().flatten(), want.flatten(), dim=0))
+        assert cos > 0.995 and abs(float(q.grad.norm()) / float(want.norm()) - 1) < 0.03, (name, cos)
+    layer.eval()
+    assert layer(src, pos, ref, ss, lsi).shape == src.shape and len(layer._masks) == 3      # eval: no new masks drawn
+    ops.CACHE.invalidate()

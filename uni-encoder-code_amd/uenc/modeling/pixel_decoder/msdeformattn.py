@@ -57,9 +57,27 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.linear1 = nn.Linear(d_model, d_ffn)
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.norm2 = nn.LayerNorm(d_model)
+        self.dropout_p = dropout            # dropout1 / dropout2 / dropout3 of the reference (msdeformattn.py:111-119), training mode only
+        self._masks = []                    # the keep-masks of the last training forward, in order (for tests)
+
+    def _drop(self, t):
+        """Inverted dropout with an explicit keep-mask (torch.nn.Dropout semantics: x * mask / keep_prob)."""
+        keep = 1.0 - self.dropout_p
+        mask = torch.rand(t.shape, device=t.device) < keep
+        self._masks.append(mask)
+        return t * (mask.to(t.dtype) / keep)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, level_embed=None):
         a = self.self_attn
+        if self.training and self.dropout_p > 0.0:
+            # training with dropout: the layer op by op (same kernels), masks applied between them as in the reference (:121-142)
+            self._masks = []
+            q = src if pos is None else src + pos
+            h = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+            src = ops.layer_norm(src + self._drop(h.float()), self.norm1.weight, self.norm1.bias)
+            t = self._drop(F.relu(ops.linear(src, self.linear1.weight, self.linear1.bias)))
+            t = ops.linear(t, self.linear2.weight, self.linear2.bias)
+            return ops.layer_norm(src + self._drop(t.float()), self.norm2.weight, self.norm2.bias)
         if (level_embed is not None and pos is not None and padding_mask is None and reference_points.shape[-1] == 2
                 and a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16):
             # the whole layer as one autograd node (ops.DeformEncoderLayerFn); `pos` is then a constant and the gradient of
@@ -130,6 +148,8 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         src = torch.cat(srcs_tok, 1)
         a = self.encoder.layers[0].self_attn
         fused = a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16
+        if self.training and self.encoder.layers[0].dropout_p > 0.0:
+            fused = False                       # dropout masks sit between the layer's ops: composed path
         if fused:
             # pos = sine embedding + level embedding: a constant map for the fused layers (one period (S, C), shared by the
             # batch), which return the level embedding's gradient themselves
