@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
-    return float((a - b).norm() / (b.norm() + 1e-12))
+    return float((a - b).norm().detach() / (b.norm().detach() + 1e-12))
 
 
 @pytest.fixture(scope="module")
@@ -186,4 +186,56 @@ def test_nat_layer_drop_path_training(U, H, W):
     assert rel(y, y2) < 1.5e-2 and rel(x.grad, x2.grad) < 2e-2
     bad = [(n, rel(q.grad, sd[p + "." + n].grad)) for n, q in layer.named_parameters() if rel(q.grad, sd[p + "." + n].grad) > 5e-2]
     assert not bad, bad
+    ops.CACHE.invalidate()
+
+
+def test_full_model_with_dinat_backbone(U):
+    """BASELINE configs[4] in small: OneFormer with the D2DiNAT backbone + MSDeformAttn pixel decoder + 150-query decoder, built
+    through the registries from cfg, forward + backward against the oracle composed from dinat_ref (backbone) and torch_ref
+    (decoders).  Free-running (the boolean attention masks are thresholded intermediate predictions): the Swin full-model
+    test's free-running bounds apply (logits / masks within 0.15, loss within 10 %), gradients by direction."""
+    from oracle import dinat_ref as D, fill, torch_ref as T
+    from uenc import ops
+    from uenc.d2 import get_cfg, build_model
+    from uenc.config import add_common_config, add_dinat_config, add_swin_config, add_uni_encoder_config
+    ops.CACHE.invalidate()
+    cfg = get_cfg()
+    add_common_config(cfg); add_swin_config(cfg); add_dinat_config(cfg); add_uni_encoder_config(cfg)
+    dil = [[1, 2], [1, 2], [1, 1], [1]]
+    cfg.merge_from_list([
+        "MODEL.META_ARCHITECTURE", "OneFormer", "MODEL.BACKBONE.NAME", "D2DiNAT", "MODEL.DiNAT.EMBED_DIM", 64, "MODEL.DiNAT.MLP_RATIO", 2.0,
+        "MODEL.DiNAT.DEPTHS", [2, 2, 2, 1], "MODEL.DiNAT.NUM_HEADS", [2, 4, 8, 16], "MODEL.DiNAT.KERNEL_SIZE", 3, "MODEL.DiNAT.DILATIONS", dil,
+        "MODEL.SEM_SEG_HEAD.NAME", "OneFormerHead", "MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME", "MSDeformAttnPixelDecoder",
+        "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 19, "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.IN_FEATURES", ["res2", "res3", "res4", "res5"],
+        "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", 6, "MODEL.ONE_FORMER.TRANSFORMER_IN_FEATURE", "multi_scale_pixel_decoder",
+        "MODEL.ONE_FORMER.NUM_OBJECT_QUERIES", 150, "MODEL.ONE_FORMER.DEC_LAYERS", 10, "MODEL.IS_TRAIN", False,
+        "MODEL.PIXEL_MEAN", [123.675, 116.280, 103.530], "MODEL.PIXEL_STD", [58.395, 57.120, 57.375], "MODEL.DEVICE", "cuda"])
+    m = build_model(cfg)
+    fill.fill_module(m, "")
+    m.eval()
+    g = torch.Generator().manual_seed(21)
+    imgs = [torch.randint(0, 256, (3, 128, 192), generator=g).float() for _ in range(2)]
+    batch = [{"left_image": im, "task": t, "type": "segmentation"} for im, t in zip(imgs, ("The task is panoptic", "The task is semantic"))]
+    out, _ = m.forward_features(batch)
+    loss = T.synthetic_loss(out)
+    loss.backward()
+    ops.flush_wgrads()
+    # oracle: the same weights by name
+    dcfg = D.DiNATCfg(64, 2.0, (2, 2, 2, 1), (2, 4, 8, 16), 3, dil)
+    mcfg = T.ModelCfg()
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    x = T.preprocess(imgs, mcfg)
+    tasks = T.task_embedding([b["task"] for b in batch], sd, mcfg)
+    feats = D.dinat_backbone(x, sd, dcfg)
+    mf, _, ms = T.pixel_decoder(feats, sd, mcfg.head)
+    want = T.transformer_decoder(ms, mf, tasks, sd, mcfg.head)
+    wl = T.synthetic_loss(want)
+    wl.backward()
+    assert rel(out["pred_logits"], want["pred_logits"]) < 0.15 and rel(out["pred_masks"], want["pred_masks"]) < 0.15
+    assert abs(float(loss) / float(wl) - 1) < 0.1
+    cos = []
+    for name, p in m.named_parameters():
+        if name.startswith("backbone.") and p.grad is not None and sd[name].grad is not None and p.numel() >= 4096:
+            cos.append(float(torch.nn.functional.cosine_similarity(p.grad.flatten().float().cpu(), sd[name].grad.flatten(), dim=0)))
+    assert len(cos) > 20 and sorted(cos)[len(cos) // 10] > 0.9, sorted(cos)[:5]      # 90 % of the backbone's weight gradients within cos 0.9
     ops.CACHE.invalidate()
