@@ -239,3 +239,37 @@ def test_full_model_with_dinat_backbone(U):
             cos.append(float(torch.nn.functional.cosine_similarity(p.grad.flatten().float().cpu(), sd[name].grad.flatten(), dim=0)))
     assert len(cos) > 20 and sorted(cos)[len(cos) // 10] > 0.9, sorted(cos)[:5]      # 90 % of the backbone's weight gradients within cos 0.9
     ops.CACHE.invalidate()
+
+
+def test_full_size_backbones_run(U):
+    """BASELINE configs[1] (Swin-T backbone forward, bs 4, 1024 x 2048) and the backbone of configs[4] (DiNAT-L, kernel 7, dilations
+    up to 16, bs 2, 1024 x 2048, forward + backward) at their own sizes: shapes, finiteness, run-to-run determinism of the forward."""
+    from uenc import ops
+    from uenc.modeling.backbone.swin import SwinTransformer
+    from uenc.modeling.backbone.dinat import DiNAT
+    from oracle import fill
+    ops.CACHE.invalidate()
+    g = torch.Generator().manual_seed(0)
+    swin = SwinTransformer(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7).cuda()
+    fill.fill_module(swin, "backbone.")
+    swin.eval()
+    img4 = torch.randn(4, 3, 1024, 2048, generator=g).cuda()
+    with torch.no_grad():
+        a, b = swin(img4), swin(img4)
+    for i, k in enumerate(("res2", "res3", "res4", "res5")):
+        assert tuple(a[k].shape) == (4, 96 * 2 ** i, 256 >> i, 512 >> i) and torch.isfinite(a[k]).all() and torch.equal(a[k], b[k])
+    del swin, a, b, img4
+    dil = [[1, 16, 1], [1, 8, 1, 8], [1, 4] * 9, [1, 2, 1, 2, 1]]
+    m = DiNAT(embed_dim=192, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[6, 12, 24, 48], kernel_size=7, dilations=dil).cuda()
+    fill.fill_module(m, "backbone.")
+    m.eval()
+    img = torch.randn(2, 3, 1024, 2048, generator=g).cuda()
+    with torch.no_grad():
+        o1, o2 = m(img), m(img)
+    for i, k in enumerate(("res2", "res3", "res4", "res5")):
+        assert tuple(o1[k].shape) == (2, 192 * 2 ** i, 256 >> i, 512 >> i) and torch.isfinite(o1[k]).all() and torch.equal(o1[k], o2[k])
+    outs = m(img)
+    sum(o.float().square().mean() for o in outs.values()).backward()
+    ops.flush_wgrads()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    ops.CACHE.invalidate()
