@@ -246,6 +246,146 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Skinny variant for the GEMMs with a handful of output tiles (the transformer decoder: M = B * 150 query rows, N = 256 ... 2048,
+// K up to 2048; ~250 launches per step that ran 6 ... 48 workgroups of the 128-tile kernel for 10 ... 25 us each, every k-tile
+// paying a full memory latency).  Here a workgroup owns a 64 x 64 tile and its four waves split the K range between them:
+// fragments go global -> registers directly in MFMA layout (nothing is shared between waves, so no LDS staging), 4 k-steps
+// (32 loads per lane) in flight per iteration, the four partial tiles are summed through LDS and the epilogue runs once.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int OUT_F32>
+__device__ __forceinline__ void epilogue8(const GemmNT& p, int m, int n, bool full8, float (&v)[8]) {
+    if (EPI == EPI_GELU) {
+        if (p.aux_out != nullptr) {
+            bf16x8 pre;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pre[r] = (bf16)v[r];
+            bf16* dst = p.aux_out + (long)m * p.ldaux_out + n;
+            if (full8) *(bf16x8*)dst = pre;
+            else { bf16x4 q4; q4[0] = pre[0]; q4[1] = pre[1]; q4[2] = pre[2]; q4[3] = pre[3]; *(bf16x4*)dst = q4; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+    } else if (EPI == EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (EPI == EPI_RESIDUAL) {
+        const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+        const float4 r0 = *(const float4*)rp;
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
+    } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
+        const bf16* ap = (const bf16*)p.aux + (long)m * p.ldaux + n;
+        bf16x8 sv;
+        if (full8) sv = *(const bf16x8*)ap;
+        else {
+            const bf16x4 q4 = *(const bf16x4*)ap;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sv[r] = q4[r]; sv[4 + r] = (bf16)0.f; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            v[r] = (EPI == EPI_MUL_DGELU) ? v[r] * dgelu_f((float)sv[r]) : (((float)sv[r] > 0.f) ? v[r] : 0.f);
+    }
+    if (OUT_F32) {
+        float* c = (float*)p.C + (long)m * p.ldc + n;
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+        bf16* c = (bf16*)p.C + (long)m * p.ldc + n;
+        if (full8) *(bf16x8*)c = o;
+        else { bf16x4 q4; q4[0] = o[0]; q4[1] = o[1]; q4[2] = o[2]; q4[3] = o[3]; *(bf16x4*)c = q4; }
+    }
+}
+
+template <int EPI, int OUT_F32, int A_F32>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNT p) {
+    constexpr int LDP = 68;                                   // 64 + 4: the accumulator writes are bank-conflict free
+    __shared__ __attribute__((aligned(16))) float part[4 * 64 * LDP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int mt = blockIdx.x / p.tiles_n, nt = blockIdx.x - mt * p.tiles_n;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const int per = (((p.K + 31) >> 5) + 3) >> 2;             // 32-wide k-steps per wave
+    const int kb = wave * per * 32, ke = min(p.K, kb + per * 32);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long aoff[4], woff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        aoff[j] = (long)min(m0 + j * 16 + fr, p.M - 1) * p.lda;
+        woff[j] = (long)min(n0 + j * 16 + fr, p.N - 1) * p.ldw;
+    }
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int k = kb; k < ke; k += 128) {
+        u32x4 xa[4][4], wa[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kk = k + s * 32 + 8 * fg;
+            const bool ok = kk < ke;
+            const int kc = min(kk, p.K - 8);                  // clamped address, masked value: the loads stay unconditional
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (A_F32) {
+                    const float* ap = (const float*)p.A + aoff[j] + kc;
+                    const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
+                    const bf16x8 r = cvt8(a0, a1);
+                    xa[s][j] = ok ? *(const u32x4*)&r : z;
+                } else {
+                    const u32x4 v = *(const u32x4*)((const bf16*)p.A + aoff[j] + kc);
+                    xa[s][j] = ok ? v : z;
+                }
+                const u32x4 w = *(const u32x4*)(p.W + woff[j] + kc);
+                wa[s][j] = ok ? w : z;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = mfma16(*(const bf16x8*)&wa[s][i], *(const bf16x8*)&xa[s][j], acc[i][j]);
+    }
+    // acc[i][j][r] = C[m = j*16 + fr][n = i*16 + 4*fg + r]
+    float* mine = part + wave * 64 * LDP;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(mine + (j * 16 + fr) * LDP + i * 16 + 4 * fg) = acc[i][j];
+    __syncthreads();
+    const int row = t >> 2, m = m0 + row;
+    if (m >= p.M) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = (t & 3) * 16 + h * 8, n = n0 + c;
+        if (n >= p.N) continue;
+        const bool full8 = (n + 8 <= p.N);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 a0 = *(const f32x4*)(part + (w * 64 + row) * LDP + c), a1 = *(const f32x4*)(part + (w * 64 + row) * LDP + c + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += a0[r]; v[4 + r] += a1[r]; }
+        }
+        if (p.bias != nullptr) {
+            const float4 b0 = *(const float4*)(p.bias + n);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+        epilogue8<EPI, OUT_F32>(p, m, n, full8, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Large-tile variant for the GEMMs that carry most of the FLOPs (stage 3 / 4 of the backbone,
 // K % 64 == 0, bf16 A): 256 x 256 x 64 tile, 8 waves (2 x 4), each wave 128(m) x 64(n) = 8 x 4
 // MFMA tiles (128 accumulator VGPRs), one workgroup per CU.  Operands go global -> LDS directly
@@ -619,6 +759,38 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         if (epilogue == EPI_MUL_DGELU || epilogue == EPI_MUL_DRELU) bytes += mn * 2;
         if (aux_out != nullptr) bytes += mn * 2;
         uenc_prof_begin(big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream, batch * bytes);
+    }
+    // few output tiles (the decoder's M = 300-row GEMMs): the K-split 64 x 64 kernel
+    const long tiles128 = (long)p.tiles_m * p.tiles_n;
+    if (!big && batch == 1 && !p.atomic && !partials && tiles128 <= 32 && K >= 64 && !(p.variant & 1024)) {
+        GemmNT q = p;
+        q.tiles_m = (M + 63) / 64; q.tiles_n = (N + 63) / 64;
+        const dim3 sgrid(q.tiles_m * q.tiles_n);
+#define LAUNCHS(E, F)                                                                                                      \
+        do {                                                                                                               \
+            if (q.a_f32) hipLaunchKernelGGL((gemm_nt_skinny_kernel<E, F, 1>), sgrid, block, 0, stream, q);               \
+            else hipLaunchKernelGGL((gemm_nt_skinny_kernel<E, F, 0>), sgrid, block, 0, stream, q);                       \
+        } while (0)
+        bool launched = true;
+        if (c_dtype == UENC_F32) {
+            if (epilogue == EPI_NONE) LAUNCHS(EPI_NONE, 1);
+            else if (epilogue == EPI_RESIDUAL) LAUNCHS(EPI_RESIDUAL, 1);
+            else if (epilogue == EPI_RELU) LAUNCHS(EPI_RELU, 1);
+            else launched = false;
+        } else {
+            switch (epilogue) {
+                case EPI_NONE: LAUNCHS(EPI_NONE, 0); break;
+                case EPI_GELU: LAUNCHS(EPI_GELU, 0); break;
+                case EPI_RELU: LAUNCHS(EPI_RELU, 0); break;
+                case EPI_MUL_DGELU: LAUNCHS(EPI_MUL_DGELU, 0); break;
+                case EPI_MUL_DRELU: LAUNCHS(EPI_MUL_DRELU, 0); break;
+                default: launched = false; break;
+            }
+        }
+#undef LAUNCHS
+        if (!launched) return UENC_EINVAL;
+        if (prof) uenc_prof_end(stream);
+        UENC_LAUNCH_RET();
     }
     if (big) {
         int rc = UENC_EINVAL;
