@@ -1,3 +1,5 @@
+"""Kernel-duration floor of tiny launches (run under rocprofv3 --kernel-trace --stats): a 1 K-element cast, an in-place add, a
+300-row LayerNorm and a 300 x 256 x 256 GEMM, 50 times each.  Measured: 1.2 us / 1.5 us / 3.9 us / 8.1 us."""
 import sys, torch
 sys.path.insert(0, '/root/repo/uni-encoder-code_amd')
 from uenc import kernels as K
