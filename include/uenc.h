@@ -154,6 +154,14 @@ int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtyp
 int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats, const float* gamma,
                        const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* dx16,
                        float* part_ws, void* stream);
+/* PatchMerging's pad-to-even + 2x2 strided gather + concat (order (0,0), (1,0), (0,1), (1,1)) + LayerNorm(4C) as one pass
+ * (reference model/modeling/backbone/swin.py:311-334; the 4C -> 2C reduction GEMM follows): x (B, H, W, C) fp32 ->
+ * y (B * ceil(H/2) * ceil(W/2), 4C) bf16, stats (rows, 2).  Backward: dy (rows, 4C) bf16 | fp32 -> dx (B, H, W, C) fp32 written
+ * completely; dgamma / dbeta (4C) accumulated; part_ws as for uenc_layernorm_bwd. */
+int uenc_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, void* y, float* stats, int B, int H, int W,
+                            int C, float eps, void* stream);
+int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* stats, const float* gamma, float* dx,
+                            float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, void* stream);
 
 /* ---- shifted-window attention (head_dim 32, window <= 12) ---------------------------------------------
  * Replaces F.pad -> torch.roll -> window_partition -> WindowAttention core -> window_reverse -> roll -> crop,

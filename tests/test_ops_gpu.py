@@ -484,3 +484,23 @@ def test_deform_encoder_layer_training_dropout(ops):
     layer.eval()
     assert layer(src, pos, ref, ss, lsi).shape == src.shape and len(layer._masks) == 3      # eval: no new masks drawn
     ops.CACHE.invalidate()
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 64), (1, 9, 13, 96), (2, 7, 10, 192), (1, 5, 5, 1536)])
+def test_patch_merge_ln_fn(ops, B, H, W, C):
+    """PatchMerging gather + LayerNorm in one kernel (even and odd maps, C up to 1536) against the reference's sequence of ops
+    (pad, four strided slices, cat, LayerNorm: backbone/swin.py:311-334), forward and backward."""
+    import torch.nn.functional as F
+    x = _r(B, H, W, C, seed=1).requires_grad_()
+    g, b = _p(4 * C, seed=2, scale=0.3), _p(4 * C, seed=3, scale=0.3)
+    with torch.no_grad():
+        g.add_(1.0)
+    dy = _r(B, ((H + 1) // 2) * ((W + 1) // 2), 4 * C, seed=4)
+    y = ops.patch_merge_ln(x, g, b)
+    y.backward(dy.to(torch.bfloat16))
+    x2, g2, b2 = x.detach().clone().requires_grad_(), g.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    xp = F.pad(x2, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([xp[:, 0::2, 0::2], xp[:, 1::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
+    y2 = F.layer_norm(cat, (4 * C,), g2, b2, 1e-5)
+    y2.backward(dy.to(torch.bfloat16).float())
+    _check("y", y, y2, 5e-3); _check("dx", x.grad, x2.grad, 1e-4); _check("dg", g.grad, g2.grad, 1e-4); _check("db", b.grad, b2.grad, 1e-4)

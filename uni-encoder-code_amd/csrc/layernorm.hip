@@ -19,7 +19,31 @@ struct LnFwd {
     bf16* y16;                        // optional bf16 twin of y (the next GEMM's operand) when y is fp32
     float2* stats;                    // optional (mean, rstd) per row
     long M; int C; float eps;
+    int mgH, mgW, mgC;                // > 0: PatchMerging gather (see PatchGather): x is the (B, mgH, mgW, mgC) fp32 map, C == 4 * mgC
 };
+
+// PatchMerging (reference backbone/swin.py:311-331): output token (b, i, j) of the (ceil(H/2), ceil(W/2)) grid is the concatenation
+// [x(2i, 2j) | x(2i+1, 2j) | x(2i, 2j+1) | x(2i+1, 2j+1)] of four C-channel pixels, zeros where H or W is odd.  Folded into the
+// LayerNorm's row addressing instead of materialising the gathered (B, L/4, 4C) tensor: column c of a row lives at
+// base(b, i, j) + off(c) when its pixel is inside the map.
+struct PatchGather {
+    long base; bool ok[4];
+    __device__ __forceinline__ PatchGather(long row, int H, int W, int C) {
+        const int W2 = (W + 1) >> 1, H2 = (H + 1) >> 1;
+        const int j = (int)(row % W2);
+        const long r2 = row / W2;
+        const int i = (int)(r2 % H2);
+        const long b = r2 / H2;
+        base = ((b * H + 2 * i) * W + 2 * j) * C;
+        const bool y1 = 2 * i + 1 < H, x1 = 2 * j + 1 < W;
+        ok[0] = true; ok[1] = y1; ok[2] = x1; ok[3] = y1 && x1;
+    }
+};
+// column c (multiple of 4) of a gathered row: segment (c / C) -> pixel (dy = seg & 1, dx = seg >> 1), channel c % C
+__device__ __forceinline__ void patch_col(int c, int W, int C, int& seg, long& off) {
+    seg = c / C;
+    off = ((long)(seg & 1) * W + (seg >> 1)) * C + (c - seg * C);
+}
 
 __device__ __forceinline__ float4 load4(const void* base, int is_f32, long idx) {
     if (is_f32) return *(const float4*)((const float*)base + idx);
@@ -32,20 +56,28 @@ __device__ __forceinline__ void store4(void* base, int is_f32, long idx, float4 
     *(bf16x4*)((bf16*)base + idx) = o;
 }
 
-template <int NV>
+template <int NV, bool MG>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
     const float invC = 1.0f / (float)p.C;
+    int gseg[NV];
+    long goff[NV];
+    if (MG) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) patch_col(min(lane * 4 + i * 256, p.C - 4), p.mgW, p.mgC, gseg[i], goff[i]);
+    }
     for (long row = wave0; row < p.M; row += nwaves) {
         float4 v[NV];
         float s = 0.f;
+        const PatchGather pg(MG ? row : 0, MG ? p.mgH : 1, MG ? p.mgW : 1, p.mgC);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < p.C) {
-                v[i] = load4(p.x, p.x_f32, row * p.C + c);
+                if (MG) v[i] = pg.ok[gseg[i]] ? *(const float4*)((const float*)p.x + pg.base + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else v[i] = load4(p.x, p.x_f32, row * p.C + c);
                 if (p.res != nullptr) {
                     const float4 r = load4(p.res, p.res_f32, row * p.C + c);
                     v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
@@ -85,6 +117,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd p) {
     }
 }
 
+// the PatchMerging gather is a template flag: the plain LayerNorms keep their register budgets (and occupancy)
+#define LN_LAUNCH(DIR, NVV, GRID, BLOCK, SHM, STREAM, P)                                                          \
+    do {                                                                                                          \
+        if ((P).mgC > 0) hipLaunchKernelGGL((ln_##DIR##_kernel<NVV, true>), GRID, BLOCK, SHM, STREAM, P);        \
+        else hipLaunchKernelGGL((ln_##DIR##_kernel<NVV, false>), GRID, BLOCK, SHM, STREAM, P);                   \
+    } while (0)
+
+static int ln_fwd_launch(LnFwd& p, hipStream_t stream);
+
 extern "C" int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtype, float* h_out,
                                   const float* gamma, const float* beta, void* y, int y_dtype, float* stats,
                                   long M, int C, float eps, void* y16, hipStream_t stream) {
@@ -92,17 +133,22 @@ extern "C" int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, i
     LnFwd p;
     p.x = x; p.x_f32 = (x_dtype == UENC_F32); p.res = res; p.res_f32 = (res_dtype == UENC_F32);
     p.h_out = h_out; p.gamma = gamma; p.beta = beta; p.y = y; p.y_f32 = (y_dtype == UENC_F32); p.y16 = (bf16*)y16;
-    p.stats = (float2*)stats; p.M = M; p.C = C; p.eps = eps;
+    p.stats = (float2*)stats; p.M = M; p.C = C; p.eps = eps; p.mgH = p.mgW = p.mgC = 0;
+    return ln_fwd_launch(p, stream);
+}
+
+static int ln_fwd_launch(LnFwd& p, hipStream_t stream) {
+    const long M = p.M; const int C = p.C;
     long blocks = (M + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     const int nv = (C + 255) / 256;
     dim3 grid((unsigned)blocks), block(256);
-    if (nv <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, p);
-    else if (nv <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, p);
-    else if (nv <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, p);
-    else if (nv <= 8) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, stream, p);
-    else if (nv <= 16) hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(ln_fwd_kernel<24>, grid, block, 0, stream, p);
+    if (nv <= 1) LN_LAUNCH(fwd, 1, grid, block, 0, stream, p);
+    else if (nv <= 2) LN_LAUNCH(fwd, 2, grid, block, 0, stream, p);
+    else if (nv <= 4) LN_LAUNCH(fwd, 4, grid, block, 0, stream, p);
+    else if (nv <= 8) LN_LAUNCH(fwd, 8, grid, block, 0, stream, p);
+    else if (nv <= 16) LN_LAUNCH(fwd, 16, grid, block, 0, stream, p);
+    else LN_LAUNCH(fwd, 24, grid, block, 0, stream, p);
     UENC_LAUNCH_RET();
 }
 
@@ -120,9 +166,10 @@ struct LnBwd {
     float* dgamma; float* dbeta;     // accumulated
     float* part;                     // optional (gridDim.x, 2, C) block partials of dgamma / dbeta (then summed by ln_bwd_param_kernel)
     long M; int C;
+    int mgH, mgW, mgC;               // > 0: PatchMerging: h is the (B, mgH, mgW, mgC) map gathered per row, dx is scattered back to it
 };
 
-template <int NV>
+template <int NV, bool MG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][C] partials of dgamma / dbeta
     const int lane = threadIdx.x & 63;
@@ -137,16 +184,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
         const int c = lane * 4 + i * 256;
         gm[i] = c < p.C ? *(const float4*)(p.gamma + c) : ag[i];
     }
+    int gseg[NV];
+    long goff[NV];
+    if (MG) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) patch_col(min(lane * 4 + i * 256, p.C - 4), p.mgW, p.mgC, gseg[i], goff[i]);
+    }
     for (long row = wave0; row < p.M; row += nwaves) {
         const float2 st = p.stats[row];
         float4 d[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
+        const PatchGather pg(MG ? row : 0, MG ? p.mgH : 1, MG ? p.mgW : 1, p.mgC);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < p.C) {
                 d[i] = load4(p.dy, p.dy_f32, row * p.C + c);
-                const float4 hv = load4(p.h, p.h_f32, row * p.C + c);
+                float4 hv;
+                if (MG) hv = pg.ok[gseg[i]] ? *(const float4*)((const float*)p.h + pg.base + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else hv = load4(p.h, p.h_f32, row * p.C + c);
                 xh[i] = make_float4((hv.x - st.x) * st.y, (hv.y - st.x) * st.y, (hv.z - st.x) * st.y, (hv.w - st.x) * st.y);
                 ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
                 ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
@@ -170,8 +226,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
                     const float4 r = *(const float4*)(p.dres + row * p.C + c);
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
-                store4(p.dx, p.dx_f32, row * p.C + c, o);
-                if (p.dx16 != nullptr) store4(p.dx16, 0, row * p.C + c, o);
+                if (MG) {
+                    if (pg.ok[gseg[i]]) *(float4*)((float*)p.dx + pg.base + goff[i]) = o;       // every map pixel is written exactly once
+                } else {
+                    store4(p.dx, p.dx_f32, row * p.C + c, o);
+                    if (p.dx16 != nullptr) store4(p.dx16, 0, row * p.C + c, o);
+                }
             }
         }
     }
@@ -231,6 +291,8 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restri
     }
 }
 
+static int ln_bwd_launch(LnBwd& p, float* part_ws, hipStream_t stream);
+
 extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats,
                                   const float* gamma, const float* dres, void* dx, int dx_dtype, float* dgamma,
                                   float* dbeta, long M, int C, void* dx16, float* part_ws, hipStream_t stream) {
@@ -239,7 +301,13 @@ extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, i
     LnBwd p;
     p.dy = dy; p.dy_f32 = (dy_dtype == UENC_F32); p.h = h; p.h_f32 = (h_dtype == UENC_F32);
     p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32); p.dx16 = (bf16*)dx16;
-    p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C; p.mgH = p.mgW = p.mgC = 0;
+    return ln_bwd_launch(p, part_ws, stream);
+}
+
+static int ln_bwd_launch(LnBwd& p, float* part_ws, hipStream_t stream) {
+    const long M = p.M; const int C = p.C;
+    float* dgamma = p.dgamma; float* dbeta = p.dbeta;
     long blocks = (M + 3) / 4;
     const long cap = (part_ws != nullptr && dgamma != nullptr) ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
     if (blocks > cap) blocks = cap;
@@ -249,13 +317,39 @@ extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, i
     const int nv = (C + 255) / 256;
     const size_t shm = (size_t)(C > 2048 ? 1 : 4) * 2 * C * sizeof(float);      // <= 64 KB
     dim3 grid((unsigned)blocks), block(256);
-    if (nv <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, shm, stream, p);
-    else if (nv <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, shm, stream, p);
-    else if (nv <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, shm, stream, p);
-    else if (nv <= 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, shm, stream, p);
-    else if (nv <= 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, shm, stream, p);
-    else hipLaunchKernelGGL(ln_bwd_kernel<24>, grid, block, shm, stream, p);
+    if (nv <= 1) LN_LAUNCH(bwd, 1, grid, block, shm, stream, p);
+    else if (nv <= 2) LN_LAUNCH(bwd, 2, grid, block, shm, stream, p);
+    else if (nv <= 4) LN_LAUNCH(bwd, 4, grid, block, shm, stream, p);
+    else if (nv <= 8) LN_LAUNCH(bwd, 8, grid, block, shm, stream, p);
+    else if (nv <= 16) LN_LAUNCH(bwd, 16, grid, block, shm, stream, p);
+    else LN_LAUNCH(bwd, 24, grid, block, shm, stream, p);
     if (p.part != nullptr)
         hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((2 * C + 63) / 64, 16), dim3(256), 0, stream, (const float*)p.part, (int)blocks, C, dgamma, dbeta);
     UENC_LAUNCH_RET();
+}
+
+
+// ---- PatchMerging gather + LayerNorm(4C) as one pass each way (reference backbone/swin.py:311-334: pad to even, four strided
+// slices, cat, norm; the 4C -> 2C reduction GEMM follows).  x (B, H, W, C) fp32 -> y (B * ceil(H/2) * ceil(W/2), 4C) bf16;
+// backward: dy (same rows, bf16 | fp32) -> dx (B, H, W, C) fp32, every element written once (no zeroing needed). ----
+extern "C" int uenc_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, void* y, float* stats, int B, int H, int W,
+                                       int C, float eps, hipStream_t stream) {
+    UENC_CHECK_ARG(x && gamma && beta && y && stats && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && 4 * C <= 6144);
+    UENC_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    LnFwd p;
+    p.x = x; p.x_f32 = 1; p.res = nullptr; p.res_f32 = 0; p.h_out = nullptr; p.gamma = gamma; p.beta = beta; p.y = y; p.y_f32 = 0;
+    p.y16 = nullptr; p.stats = (float2*)stats; p.M = (long)B * ((H + 1) / 2) * ((W + 1) / 2); p.C = 4 * C; p.eps = eps;
+    p.mgH = H; p.mgW = W; p.mgC = C;
+    return ln_fwd_launch(p, stream);
+}
+
+extern "C" int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* stats, const float* gamma, float* dx,
+                                       float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, hipStream_t stream) {
+    UENC_CHECK_ARG(dy && x && stats && gamma && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && 4 * C <= 6144);
+    UENC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
+    LnBwd p;
+    p.dy = dy; p.dy_f32 = (dy_dtype == UENC_F32); p.h = x; p.h_f32 = 1; p.stats = (const float2*)stats; p.gamma = gamma; p.dres = nullptr;
+    p.dx = dx; p.dx_f32 = 1; p.dx16 = nullptr; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.M = (long)B * ((H + 1) / 2) * ((W + 1) / 2); p.C = 4 * C; p.mgH = H; p.mgW = W; p.mgC = C;
+    return ln_bwd_launch(p, part_ws, stream);
 }

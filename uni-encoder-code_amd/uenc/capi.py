@@ -60,6 +60,8 @@ _SIGNATURES = {
     "uenc_postproc_semantic": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_postproc_panoptic_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_postproc_panoptic_label": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_patch_merge_ln_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_patch_merge_ln_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_na2d_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_na2d_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_window_attn_bwd_ws_floats": [c_i, c_i, c_i, c_i, c_i],

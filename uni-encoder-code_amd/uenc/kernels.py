@@ -222,6 +222,28 @@ def na2d_bwd(qkv, rpb, out, dout, lse, nH: int, ks: int, dilation: int, scale: f
     return dqkv
 
 
+def patch_merge_ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """x (B, H, W, C) fp32 -> (y (B, ceil(H/2) * ceil(W/2), 4C) bf16, stats): PatchMerging's gather + LayerNorm in one pass."""
+    B, H, W, C = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and gamma.numel() == 4 * C
+    L2 = ((H + 1) // 2) * ((W + 1) // 2)
+    y = torch.empty((B, L2, 4 * C), dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty((B * L2, 2), dtype=torch.float32, device=x.device)
+    check(lib.uenc_patch_merge_ln_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, H, W, C, float(eps),
+                                      stream_ptr()), "patch_merge_ln_fwd")
+    return y, stats
+
+
+def patch_merge_ln_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, dgamma=None, dbeta=None) -> torch.Tensor:
+    B, H, W, C = x.shape
+    assert dy.is_contiguous() and dy.shape[-1] == 4 * C
+    dx = torch.empty_like(x)
+    part = _scratch("ln_bwd", 2048 * 2 * 4 * C * 4, x.device) if dgamma is not None else None
+    check(lib.uenc_patch_merge_ln_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(), ptr(dgamma),
+                                      ptr(dbeta), ptr(part), B, H, W, C, stream_ptr()), "patch_merge_ln_bwd")
+    return dx
+
+
 def relpos_expand(table: torch.Tensor, ws: int):
     """relative_position_bias_table ((2ws-1)^2, nH) fp32 -> dense (nH, NP, NP) in query-major and key-major order."""
     assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] == (2 * ws - 1) ** 2

@@ -112,11 +112,15 @@ class PatchMerging(nn.Module):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
         x = x.view(B, H, W, C)
-        if H % 2 == 1 or W % 2 == 1:
-            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
-        x = x.reshape(B, -1, 4 * C)
-        xn = ops.layer_norm(x, self.norm.weight, self.norm.bias, out_dtype=torch.bfloat16)
+        if x.dtype == torch.float32 and 4 * C <= 6144 and C % 4 == 0:
+            # pad-to-even, the four strided slices, the concat and the LayerNorm are one kernel (index arithmetic)
+            xn = ops.patch_merge_ln(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            if H % 2 == 1 or W % 2 == 1:
+                x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+            x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+            x = x.reshape(B, -1, 4 * C)
+            xn = ops.layer_norm(x, self.norm.weight, self.norm.bias, out_dtype=torch.bfloat16)
         return ops.linear(xn, self.reduction.weight, None, out_dtype=torch.float32)
 
 

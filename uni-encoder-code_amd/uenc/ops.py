@@ -1206,3 +1206,29 @@ class ConvS2Fn(torch.autograd.Function):
 def conv3x3_s2(x_nhwc, weight, bias=None):
     """x (B, H, W, Cin) channels-last -> (B, ceil(H/2), ceil(W/2), Cout) fp32."""
     return ConvS2Fn.apply(x_nhwc, weight, bias)
+
+
+class PatchMergeLnFn(torch.autograd.Function):
+    """PatchMerging's pad + 2x2 strided gather + concat + LayerNorm(4C) (reference backbone/swin.py:311-334) as one kernel each way:
+    x (B, H, W, C) fp32 -> (B, ceil(H/2) * ceil(W/2), 4C) bf16, the operand of the 4C -> 2C reduction GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y, stats = K.patch_merge_ln_fwd(xc, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(xc, stats, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma, beta = ctx.saved_tensors
+        train = gamma.requires_grad
+        dx = K.patch_merge_ln_bwd(dy if dy.is_contiguous() else dy.contiguous(), x, stats, gamma.detach(),
+                                  grad_buf(gamma) if train else None, grad_buf(beta) if train else None)
+        if train:
+            _notify(gamma, beta)
+        return dx, None, None, None
+
+
+def patch_merge_ln(x_bhwc, gamma, beta, eps: float = 1e-5):
+    return PatchMergeLnFn.apply(x_bhwc, gamma, beta, eps)
