@@ -36,11 +36,13 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
-def cast_transpose_bf16(src: torch.Tensor) -> torch.Tensor:
+def cast_transpose_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(R, C) fp32 -> (C, R) bf16."""
     assert src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous() and src.is_cuda
     R, C = src.shape
-    out = torch.empty((C, R), dtype=torch.bfloat16, device=src.device)
+    if out is None:
+        out = torch.empty((C, R), dtype=torch.bfloat16, device=src.device)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (C, R) and out.is_contiguous()
     check(lib.uenc_cast_transpose_f32_bf16(src.data_ptr(), out.data_ptr(), R, C, stream_ptr()), "cast_transpose")
     return out
 
