@@ -40,12 +40,19 @@ SWIN_L = dict(EMBED_DIM=192, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[6, 12, 24, 48], WI
 GFLOP_FWD_PER_IMG = 3976.0
 
 
+# BASELINE configs[4] (not the headline): UENC_BENCH_BACKBONE=dinat swaps the backbone for DiNAT-L (kernel 7; dilations = 1 / the largest
+# that fits each stage of a 1024 x 2048 input) and tags the JSON line; metric, loss and protocol stay the same.
+DINAT_L = dict(EMBED_DIM=192, MLP_RATIO=2.0, DEPTHS=[3, 4, 18, 5], NUM_HEADS=[6, 12, 24, 48], KERNEL_SIZE=7,
+               DILATIONS=[[1, 16, 1], [1, 8, 1, 8], [1, 4] * 9, [1, 2, 1, 2, 1]])
+BACKBONE = os.environ.get("UENC_BENCH_BACKBONE", "swin").lower()
+
+
 def make_cfg(device):
     import model  # noqa: F401  (registers OneFormer, D2SwinTransformer, OneFormerHead, decoders)
-    from uenc.config import add_common_config, add_swin_config, add_uni_encoder_config
+    from uenc.config import add_common_config, add_dinat_config, add_swin_config, add_uni_encoder_config
     from uenc.d2 import get_cfg
     cfg = get_cfg()
-    add_common_config(cfg); add_swin_config(cfg); add_uni_encoder_config(cfg)
+    add_common_config(cfg); add_swin_config(cfg); add_dinat_config(cfg); add_uni_encoder_config(cfg)
     opts = ["MODEL.META_ARCHITECTURE", "OneFormer", "MODEL.BACKBONE.NAME", "D2SwinTransformer",
             "MODEL.SEM_SEG_HEAD.NAME", "OneFormerHead", "MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME", "MSDeformAttnPixelDecoder",
             "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 19, "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.MASK_DIM", 256,
@@ -56,6 +63,10 @@ def make_cfg(device):
             "MODEL.DEVICE", device]
     for k, v in SWIN_L.items():
         opts += [f"MODEL.SWIN.{k}", v]
+    if BACKBONE == "dinat":
+        opts[opts.index("D2SwinTransformer")] = "D2DiNAT"
+        for k, v in DINAT_L.items():
+            opts += [f"MODEL.DiNAT.{k}", v]
     cfg.merge_from_list(opts)
     return cfg
 
@@ -216,11 +227,13 @@ def main():
         except Exception:
             pass
         rec = {
-            "metric": "img/s fwd+bwd Swin-L 1024x2048 bs=2 per GPU", "value": round(imgs / dt, 4), "unit": "img/s",
+            "metric": "img/s fwd+bwd Swin-L 1024x2048 bs=2 per GPU" if BACKBONE != "dinat" else "img/s fwd+bwd DiNAT-L 1024x2048 bs=2 per GPU", "value": round(imgs / dt, 4), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: full OneFormer (Swin-L ws12 backbone + MSDeformAttn pixel decoder + "
-                                   "150-query masked-attention decoder), 1024x2048, fwd+bwd, synthetic loss",
+            "config": {"workload": ("BASELINE configs[2]: full OneFormer (Swin-L ws12 backbone + MSDeformAttn pixel decoder + "
+                                    "150-query masked-attention decoder), 1024x2048, fwd+bwd, synthetic loss") if BACKBONE != "dinat" else
+                                   ("BASELINE configs[4]: full OneFormer with the DiNAT-L backbone (neighbourhood attention, kernel 7), "
+                                    "1024x2048, fwd+bwd, synthetic loss [UENC_BENCH_BACKBONE=dinat; model_tflop fields do not apply]"),
                        "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
                        "model_tflop_per_step_per_gpu": round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3, 2)},
             "model_tflops_per_gpu": round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3 / (dt / args.steps), 1),
