@@ -95,6 +95,11 @@ int uenc_upsample_bilinear_tokens_bwd(const void* dy, int dy_dtype, float* dsrc,
  * in (B, H, W, C), and the adjoint dx (B, H, W, C) from dcol (B*H*W, 9*C). */
 int uenc_im2col3x3(const void* in, void* col, int B, int H, int W, int C, void* stream);
 int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, void* stream);
+/* The same for the 3x3 stride-2 pad-1 convolutions of DiNAT's ConvTokenizer / ConvDownsampler (reference
+ * model/modeling/backbone/dinat.py:17-45): col (B * ceil(H/2) * ceil(W/2), 9C) bf16 in (ky, kx, c) order; the adjoint gathers
+ * dcol back to dx (B, H, W, C) fp32, every element written once.  C % 8 == 0. */
+int uenc_im2col3x3_s2(const void* in, void* col, int B, int H, int W, int C, void* stream);
+int uenc_col2im3x3_s2(const void* dcol, float* dx, int B, int H, int W, int C, void* stream);
 
 /* ---- Linear layers ---------------------------------------------------------------------------------
  * C[m][n] = epi(alpha * (sum_k A[m][k] W[n][k] + bias[n])).  A fp32|bf16 [M][K] (lda), W bf16 [N][K] (ldw),

@@ -400,3 +400,76 @@ extern "C" int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, i
     hipLaunchKernelGGL(col2im3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)dcol, (bf16*)dx, B, H, W, C);
     UENC_LAUNCH_RET();
 }
+
+// ---- 3x3, stride 2, pad 1 convolution as a GEMM (DiNAT ConvTokenizer / ConvDownsampler, reference backbone/dinat.py:17-45) ----
+// col[(b, yo, xo)][(ky, kx, c)] = in[b, 2 yo + ky - 1, 2 xo + kx - 1, c] (0 outside); Ho = ceil(H / 2), Wo = ceil(W / 2)
+__global__ __launch_bounds__(256) void im2col3x3_s2_kernel(const bf16* __restrict__ in, bf16* __restrict__ col, int B, int H, int W, int C,
+                                                           int Ho, int Wo) {
+    const int c8n = C >> 3;
+    const long total = (long)B * Ho * Wo * 9 * c8n;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int c8 = (int)(t % c8n);
+        long r = t / c8n;
+        const int k = (int)(r % 9); r /= 9;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const int yy = 2 * yo + k / 3 - 1, xx = 2 * xo + k % 3 - 1;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const u32x4*)(in + (((long)b * H + yy) * W + xx) * C + c8 * 8);
+        *(u32x4*)(col + t * 8) = v;
+    }
+}
+
+// dx[b, y, x, c] (fp32) = sum over the taps (ky, kx) with y + 1 - ky and x + 1 - kx even and the output pixel in range of
+// dcol[(b, (y + 1 - ky) / 2, (x + 1 - kx) / 2)][(ky, kx, c)]: a gather, every dx element written once
+__global__ __launch_bounds__(256) void col2im3x3_s2_kernel(const bf16* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W, int C,
+                                                           int Ho, int Wo) {
+    const int c8n = C >> 3;
+    const long total = (long)B * H * W * c8n;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int c8 = (int)(t % c8n);
+        long r = t / c8n;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = y + 1 - ky;
+            if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = x + 1 - kx;
+                if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+                const bf16x8 v = *(const bf16x8*)(dcol + ((((long)b * Ho + (ty >> 1)) * Wo + (tx >> 1)) * 9 + ky * 3 + kx) * C + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            }
+        }
+        float* o = dx + t * 8;
+        *(float4*)o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *(float4*)(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+extern "C" int uenc_im2col3x3_s2(const void* in, void* col, int B, int H, int W, int C, hipStream_t stream) {
+    UENC_CHECK_ARG(in && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (((uintptr_t)in | (uintptr_t)col) & 15) == 0);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)B * Ho * Wo * 9 * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(im2col3x3_s2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)in, (bf16*)col, B, H, W, C, Ho, Wo);
+    UENC_LAUNCH_RET();
+}
+
+extern "C" int uenc_col2im3x3_s2(const void* dcol, float* dx, int B, int H, int W, int C, hipStream_t stream) {
+    UENC_CHECK_ARG(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (((uintptr_t)dcol | (uintptr_t)dx) & 15) == 0);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)B * H * W * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(col2im3x3_s2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)dcol, dx, B, H, W, C, Ho, Wo);
+    UENC_LAUNCH_RET();
+}
+

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "uenc_postproc_panoptic_label": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_patch_merge_ln_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_patch_merge_ln_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "uenc_im2col3x3_s2": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "uenc_col2im3x3_s2": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_na2d_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_na2d_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_window_attn_bwd_ws_floats": [c_i, c_i, c_i, c_i, c_i],

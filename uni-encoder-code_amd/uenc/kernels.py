@@ -199,6 +199,23 @@ def postproc_panoptic_label(mask_logits: torch.Tensor, ids: torch.Tensor, segid:
     return seg
 
 
+def im2col3x3_s2(x16: torch.Tensor) -> torch.Tensor:
+    """x (B, H, W, C) bf16 channels-last -> patch matrix (B * ceil(H/2) * ceil(W/2), 9C) bf16 of the 3x3 stride-2 pad-1 convolution."""
+    B, H, W, C = x16.shape
+    assert x16.dtype == torch.bfloat16 and x16.is_contiguous() and C % 8 == 0
+    col = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), 9 * C), dtype=torch.bfloat16, device=x16.device)
+    check(lib.uenc_im2col3x3_s2(x16.data_ptr(), col.data_ptr(), B, H, W, C, stream_ptr()), "im2col3x3_s2")
+    return col
+
+
+def col2im3x3_s2(dcol: torch.Tensor, B: int, H: int, W: int, C: int) -> torch.Tensor:
+    """adjoint of im2col3x3_s2: (rows, 9C) bf16 -> (B, H, W, C) fp32."""
+    assert dcol.dtype == torch.bfloat16 and dcol.is_contiguous() and dcol.shape[1] == 9 * C
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dcol.device)
+    check(lib.uenc_col2im3x3_s2(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "col2im3x3_s2")
+    return dx
+
+
 def na2d_fwd(qkv: torch.Tensor, rpb: Optional[torch.Tensor], nH: int, ks: int, dilation: int, scale: float, need_lse: bool = True):
     """Neighbourhood attention on qkv (B, H, W, 3C) bf16 (C = nH * 32) -> out (B, H, W, C) bf16, lse (B, nH, H, W) fp32."""
     B, H, W, C3 = qkv.shape

@@ -1167,7 +1167,9 @@ class ConvS2Fn(torch.autograd.Function):
         Co = weight.shape[0]
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
         Kp = -(-9 * C // 8) * 8
-        col = ConvS2Fn._patches(x if x.dtype == BF16 else x.to(BF16), Ho, Wo, Kp)
+        x16 = x if x.dtype == BF16 else x.to(BF16)
+        # patch matrix by the HIP gather when the channel count allows 16-byte pieces, else by strided slices (the 3-channel image)
+        col = K.im2col3x3_s2(x16.contiguous()) if C % 8 == 0 else ConvS2Fn._patches(x16, Ho, Wo, Kp)
         Np = -(-Co // 8) * 8
         out = K.gemm_nt(col, ConvS2Fn._wmat(weight, Kp, False), bias=_bias_pad(bias, Np), out_dtype=F32)
         ctx.save_for_backward(col, weight, bias)
@@ -1186,12 +1188,18 @@ class ConvS2Fn(torch.autograd.Function):
             dy2 = F.pad(dy2, (0, Np - Co))
         dx = None
         if ctx.needs_input_grad[0]:
-            dcol = K.gemm_nt(dy2, ConvS2Fn._wmat(weight, Kp, True), out_dtype=F32).view(B, Ho, Wo, Kp)
-            dxp = dcol.new_zeros((B, 2 * Ho + 2, 2 * Wo + 2, C))
-            for t in range(9):                                            # adjoint of the strided gather
-                dyy, dxx = divmod(t, 3)
-                dxp[:, dyy:dyy + 2 * Ho:2, dxx:dxx + 2 * Wo:2, :] += dcol[..., t * C:(t + 1) * C]
-            dx = dxp[:, 1:1 + H, 1:1 + W, :].to(ctx.in_dtype)
+            if C % 8 == 0:
+                dcol = K.gemm_nt(dy2, ConvS2Fn._wmat(weight, Kp, True))                          # (M, 9C) bf16
+                dx = K.col2im3x3_s2(dcol, B, H, W, C)
+                if ctx.in_dtype != F32:
+                    dx = dx.to(ctx.in_dtype)
+            else:
+                dcol = K.gemm_nt(dy2, ConvS2Fn._wmat(weight, Kp, True), out_dtype=F32).view(B, Ho, Wo, Kp)
+                dxp = dcol.new_zeros((B, 2 * Ho + 2, 2 * Wo + 2, C))
+                for t in range(9):                                        # adjoint of the strided gather
+                    dyy, dxx = divmod(t, 3)
+                    dxp[:, dyy:dyy + 2 * Ho:2, dxx:dxx + 2 * Wo:2, :] += dcol[..., t * C:(t + 1) * C]
+                dx = dxp[:, 1:1 + H, 1:1 + W, :].to(ctx.in_dtype)
         if weight.requires_grad:
             dw = torch.zeros((Np, Kp), dtype=F32, device=dy.device)
             db = torch.zeros((Np,), dtype=F32, device=dy.device) if bias is not None else None
