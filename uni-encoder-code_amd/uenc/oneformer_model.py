@@ -129,12 +129,18 @@ class OneFormer(nn.Module):
             else:
                 if mask_pred_results is None:
                     mask_pred_results = self.upsample_masks(outputs["pred_masks"], padded)
-                mp = mask_pred_results[i][:, : image_size[0], : image_size[1]]
-                if (height, width) != tuple(image_size):
-                    mp = F.interpolate(mp[None], size=(height, width), mode="bilinear", align_corners=False)[0]
+                def postprocess(t):      # detectron2 sem_seg_postprocess: crop the padding, resize to the requested resolution
+                    t = t[:, : image_size[0], : image_size[1]]
+                    if (height, width) != tuple(image_size):
+                        t = F.interpolate(t[None], size=(height, width), mode="bilinear", align_corners=False)[0]
+                    return t
+                mp = postprocess(mask_pred_results[i])
                 r["pred_masks"] = mp
                 if self.semantic_on:
-                    r["sem_seg"] = self.semantic_inference(mask_cls, mp)
+                    if self.sem_seg_postprocess_before_inference:
+                        r["sem_seg"] = self.semantic_inference(mask_cls, mp)
+                    else:                # reference :283-289: inference on the padded masks, then crop / resize of the class map
+                        r["sem_seg"] = postprocess(self.semantic_inference(mask_cls, mask_pred_results[i]))
                 if self.panoptic_on:
                     r["panoptic_seg"] = self.panoptic_inference(mask_cls, mp)
                 if self.instance_on:
