@@ -257,6 +257,35 @@ int uenc_postproc_panoptic_stats(const float* mask_logits, const float* score, i
 int uenc_postproc_panoptic_label(const float* mask_logits, const int* ids, const int* segid, int* seg, int Q, int hl, int wl, int Hp,
                                  int Wp, int Ho, int Wo, void* stream);
 
+/* ---- fp32 "exact" arithmetic mode (csrc/exact.hip; UENC_EXACT=1 / uenc.ops.set_exact) -----------------------------------
+ * The reference computes in fp32 end to end (AMP off, configs/cityscapes/swin/unified_encoder_cityscapes.yaml:27-28; the pixel
+ * decoder forces fp32, pixel_decoder/msdeformattn.py:336,343).  These entry points run the contractions of the path on fp32
+ * operands with fp32 accumulation (v_mfma_f32_16x16x4_f32 for the GEMMs, VALU for the two attention cores), so that a
+ * deviation from the reference can be split into bf16 rounding (the product's mode) and everything else (must be ~1e-5).
+ * A verification mode: same call sites, same epilogues, no performance claim.
+ *   gemm_nt_f32:  C = epi(alpha * (A W^T + bias)), all fp32, K % 4 == 0, lda / ldw % 4 == 0; aux / aux_out fp32 (the
+ *                 GELU pre-activation, ReLU output or residual of the UENC_EPI_* epilogues); accumulate: C += (EPI_NONE only)
+ *   gemm_tn_f32:  dW (N, K) += dY^T X, db (N) += column sums of dY (db may be NULL); dY (M, N), X (M, K) fp32, N, K % 4 == 0
+ *   window_attn_f32_{fwd,bwd}: qkv (B, H, W, 3C) fp32, qkv_bias (3C), table ((2ws-1)^2, nH) = relative_position_bias_table,
+ *                 out / dout (B, H, W, C); same pad / shift / mask semantics as uenc_window_attn_* (model/modeling/backbone/
+ *                 swin.py:250-289, :131-171, :414-440).  bwd: dqkv written, dtable and dbias_pad (3C) accumulated (atomics)
+ *   mha_f32_{fwd,bwd}: the decoder's nn.MultiheadAttention cores, tensor contract of uenc_mha_* with fp32 tensors; lse (B, nH, Lq);
+ *                 bwd: dq written, dk / dv (zeroed by the caller) accumulated, delta (B, nH, Lq) scratch */
+int uenc_gemm_nt_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias,
+                     int epilogue, const float* aux, long ldaux, float* aux_out, long ldaux_out, float alpha, int accumulate, void* stream);
+int uenc_gemm_tn_f32(const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db, int M, int N, int K, void* stream);
+int uenc_window_attn_f32_fwd(const float* qkv, const float* qkv_bias, const float* table, float* out, int B, int H, int W, int C, int nH,
+                             int ws, int shift, float scale, void* stream);
+int uenc_window_attn_f32_bwd(const float* qkv, const float* qkv_bias, const float* table, const float* dout, float* dqkv, float* dtable,
+                             float* dbias_pad, int B, int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
+int uenc_mha_f32_fwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
+                     const uint8_t* mask, long mask_row_stride, float* out, long os0, long os1, float* lse, int B, int nH, int Lq, int S,
+                     float scale, void* stream);
+int uenc_mha_f32_bwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
+                     const uint8_t* mask, long mask_row_stride, const float* out, long os0, long os1, const float* lse, const float* dout,
+                     long gos0, long gos1, float* dq, long dqs0, long dqs1, float* dk, long dks0, long dks1, float* dv, long dvs0, long dvs1,
+                     float* delta, int B, int nH, int Lq, int S, float scale, void* stream);
+
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */
 int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile), 1 gemm_tn*, 4 gemm_nt256 */, double* ms_total, double* flops_total, long* launches);

@@ -17,6 +17,9 @@ Fixture list:
   F8 pos_embed_sine    5x7
   F9 task_tokens       tokenizer ids of the three task prompts + task_mlp output
   F10 model_fwd_bwd    small full model: loss and selected parameter gradients
+  F11 decoder_contrastive  F7's inputs through the decoder built with is_train=True: `contrastive_logits` and gradients of a loss on it
+
+`python -m oracle.make_golden NAME [NAME ...]` regenerates only the named fixtures (F11: decoder_contrastive).
 """
 import json
 import os
@@ -59,10 +62,10 @@ def build_ref_pixel_decoder(ref, ch):
     return pd
 
 
-def build_ref_decoder(ref):
+def build_ref_decoder(ref, is_train=False):
     dec = ref.dec.ContrastiveMultiScaleMaskedTransformerDecoder(
         256, True, num_classes=19, hidden_dim=256, num_queries=150, nheads=8, dropout=0.1,
-        dim_feedforward=2048, enc_layers=0, is_train=False, dec_layers=9, class_dec_layers=2,
+        dim_feedforward=2048, enc_layers=0, is_train=is_train, dec_layers=9, class_dec_layers=2,
         pre_norm=False, mask_dim=256, enforce_input_project=False, use_task_norm=True)
     dec.eval()
     fill.fill_module(dec, "sem_seg_head.predictor.")
@@ -77,6 +80,25 @@ def build_ref_swin(ref, cfg: T.SwinCfg):
     return m
 
 
+def decoder_contrastive(ref):
+    """F11: the reference decoder constructed with is_train=True (oneformer_transformer_decoder.py:273, 477-480) on F7's inputs.
+    Loss = mean(contrastive_logits^2) + 0.1 * synthetic loss; stores the contrastive tensor and three gradients."""
+    f7 = np.load(os.path.join(OUT, "transformer_decoder.npz"))
+    mf = torch.from_numpy(f7["mask_features"])
+    ms = [torch.from_numpy(f7[f"ms{i}"]) for i in range(3)]
+    tasks = torch.from_numpy(f7["tasks"]).requires_grad_()
+    dec = build_ref_decoder(ref, is_train=True)
+    o = dec(ms, mf, tasks)
+    cl = o["contrastive_logits"]                       # (B, Q, E) after the reference's permute
+    loss = cl.square().mean() + 0.1 * T.synthetic_loss(o)
+    loss.backward()
+    named = dict(dec.named_parameters())
+    _save("decoder_contrastive", contrastive_logits=cl, loss=loss.detach(), grad_tasks=tasks.grad,
+          grad_query_embed=named["query_embed.weight"].grad,
+          grad_class_norm_weight=named["class_transformer.decoder.norm.weight"].grad,
+          grad_ct_l1_linear2_bias=named["class_transformer.decoder.layers.1.linear2.bias"].grad)
+
+
 def main():
     warnings.filterwarnings("ignore")
     assert ref_loader.available(), "needs /root/reference"
@@ -84,6 +106,11 @@ def main():
     ref = ref_loader.load()
     torch.manual_seed(0)
     manifest = {}
+    only = set(sys.argv[1:])
+    if only:
+        for name in only:
+            {"decoder_contrastive": decoder_contrastive}[name](ref)
+        return
 
     # F1 / F2: block pairs through the reference BasicLayer (builds the shift mask itself)
     for tag, C, nH, ws, H, W, seed in (("swin_pair_ws7", 96, 3, 7, 24, 40, 1), ("swin_pair_ws12", 192, 6, 12, 20, 30, 2)):
@@ -217,6 +244,7 @@ def main():
         grads[f"gradstride{i}"] = np.array(stride)
     _save("model_fwd_bwd", img0=imgs[0].byte(), img1=imgs[1].byte(), loss=loss.detach(), pred_logits=o["pred_logits"],
           pred_masks=o["pred_masks"], grad_names=np.array(pick), grad_norm=np.array(sq ** 0.5), **grads)
+    decoder_contrastive(ref)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "python -m oracle.make_golden", "torch": torch.__version__,
                    "note": "inputs + outputs of the reference's modules with name-hashed weights (oracle/fill.py)"}, f, indent=1)

@@ -395,8 +395,9 @@ def prediction_heads(out: Tensor, mf: Tensor, size, sd: SD, prefix: str):
 
 
 def transformer_decoder(ms_feats: List[Tensor], mf: Tensor, tasks: Tensor, sd: SD, cfg: HeadCfg,
-                        prefix: str = "sem_seg_head.predictor.", forced_masks=None) -> Dict[str, object]:
-    """transformer_decoder/oneformer_transformer_decoder.py:405-493 in eval mode (is_train False)."""
+                        prefix: str = "sem_seg_head.predictor.", forced_masks=None, is_train: bool = False) -> Dict[str, object]:
+    """transformer_decoder/oneformer_transformer_decoder.py:405-493 (dropout = identity).  is_train: the constructor flag
+    of :273 / :477-480 -- `contrastive_logits` is then the PRE-loop query tensor (class-transformer output + task token)."""
     nh, E = cfg.nheads, cfg.hidden_dim
     B = mf.shape[0]
     src, pos, sizes = [], [], []
@@ -426,6 +427,7 @@ def transformer_decoder(ms_feats: List[Tensor], mf: Tensor, tasks: Tensor, sd: S
         tgt = _ln(tgt + _lin(F.relu(_lin(tgt, sd, lp + ".linear1")), sd, lp + ".linear2"), sd, lp + ".norm3")
     tgt = _ln(tgt, sd, prefix + "class_transformer.decoder.norm")
     out = torch.cat([tgt, t], 1)                                    # (B, Q, E): 149 queries + task token
+    query_class = out                                               # :440 `out` (batch-first here; the reference permutes at :478)
     qpos = qe[None].expand(B, -1, -1)
     pc, pm, ams = [], [], []
     cls, masks, am = prediction_heads(out, mf, sizes[0], sd, prefix)
@@ -448,7 +450,7 @@ def transformer_decoder(ms_feats: List[Tensor], mf: Tensor, tasks: Tensor, sd: S
         pc.append(cls); pm.append(masks)
     return {"pred_logits": pc[-1], "pred_masks": pm[-1],
             "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(pc[:-1], pm[:-1])],
-            "attn_masks": ams, "contrastive_logits": None}
+            "attn_masks": ams, "contrastive_logits": query_class if is_train else None}
 
 
 # ----------------------------------------------------------------------------

@@ -35,3 +35,33 @@ def golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+# ---- parity figures: every GPU parity test records the numbers it computed (relative errors, sign agreement, gradient
+# cosines, envelope values), not only whether they passed.  Written at session end to $UENC_PARITY_OUT or, by default,
+# gpurun_out/parity.json (which gpurun merges back); the copy a round wants judged is committed as profiles/rNN_parity.json.
+_PARITY = {}
+
+
+def record_parity(test: str, **figures):
+    ent = _PARITY.setdefault(test, {})
+    for k, v in figures.items():
+        ent[k] = float(v) if isinstance(v, (int, float, np.floating)) or (torch.is_tensor(v) and v.numel() == 1) else v
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    path = os.environ.get("UENC_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_PARITY)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

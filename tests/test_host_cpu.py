@@ -105,3 +105,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_yaml_eval_tag_is_checked_before_evaluation(tmp_path):
+    """`!!python/object/apply:eval` (reference configs/.../unified_encoder_cityscapes.yaml:40) accepts arithmetic list
+    comprehensions only: attribute walks, subscripts, other calls and strings are refused before anything is evaluated."""
+    from uenc.d2 import CfgNode
+    ok = tmp_path / "ok.yaml"
+    ok.write_text('A: !!python/object/apply:eval ["[int(x * 0.1 * 384) for x in range(5, 21)]"]\n')
+    assert CfgNode.load_yaml_with_base(str(ok))["A"][:3] == [192, 230, 268]
+    for expr in ("().__class__.__base__.__subclasses__()", "[x for x in (1).__class__.__mro__]", "__import__('os').system('true')",
+                 "[int(x) for x in range(3)][0]", "'a' * 3", "(lambda: 1)()"):
+        bad = tmp_path / "bad.yaml"
+        bad.write_text(f'A: !!python/object/apply:eval ["{expr}"]\n')
+        with pytest.raises(ValueError):
+            CfgNode.load_yaml_with_base(str(bad))

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,7 @@ def test_swin_block_pair_golden(U, tag):
             blk.H, blk.W = H, W
         y0 = layer.blocks[0](g["x"].cuda(), None)
         y = layer(g["x"].cuda(), H, W)[0]
+    record_parity(f"bf16/{tag}", y_block0=rel(y0, g["y_block0"]), y=rel(y, g["y"]))
     assert rel(y0, g["y_block0"]) < 1.5e-2
     assert rel(y, g["y"]) < 1.5e-2
 
@@ -58,6 +59,7 @@ def test_swin_t_backbone_golden(U):
     assert m.eval() is None      # the reference's train() returns None (swin.py:680-683): eval() cannot be chained
     with torch.no_grad():
         o = m(g["img"].cuda())
+    record_parity("bf16/swin_t_96x160", **{k: rel(o[k], g[k]) for k in ("res2", "res3", "res4", "res5")})
     for k in ("res2", "res3", "res4", "res5"):
         assert o[k].shape == g[k].shape
         assert rel(o[k], g[k]) < 1.5e-2, k
@@ -70,6 +72,7 @@ def test_patch_merging_golden(U):
     pm = _fill(PatchMerging(C), "backbone.layers.0.downsample.").cuda()
     with torch.no_grad():
         y = pm(g["x"].cuda(), H, W)
+    record_parity("bf16/patch_merging", y=rel(y, g["y"]))
     assert rel(y, g["y"]) < 1e-2
 
 
@@ -94,6 +97,7 @@ def test_pixel_decoder_golden(U):
     pd, _ = _head_modules(U, ch)
     with torch.no_grad():
         mf, _, ms = pd.forward_features({k: g[k].cuda() for k in ch})
+    record_parity("bf16/pixel_decoder", mask_features=rel(mf, g["mask_features"]), **{f"ms{i}": rel(ms[i], g[f"ms{i}"]) for i in range(3)})
     assert rel(mf, g["mask_features"]) < 2e-2
     for i in range(3):
         assert rel(ms[i], g[f"ms{i}"]) < 2e-2, i
@@ -120,6 +124,10 @@ def test_transformer_decoder_golden(U):
     with torch.no_grad():
         o = dec(feats, g["mask_features"].cuda(), g["tasks"].cuda())
     dec.forced_attn_masks = None
+    record_parity("bf16/transformer_decoder_forced_masks", pred_logits=rel(o["pred_logits"], g["pred_logits"]),
+                  pred_masks=rel(o["pred_masks"], g["pred_masks"]),
+                  aux_logits=[rel(a["pred_logits"], g[f"aux{i}_logits"]) for i, a in enumerate(o["aux_outputs"])],
+                  aux_masks=[rel(a["pred_masks"], g[f"aux{i}_masks"]) for i, a in enumerate(o["aux_outputs"])])
     for i, a in enumerate(o["aux_outputs"]):
         assert rel(a["pred_logits"], g[f"aux{i}_logits"]) < 2e-2, i
         assert rel(a["pred_masks"], g[f"aux{i}_masks"]) < 2e-2, i
@@ -137,6 +145,10 @@ def test_transformer_decoder_golden(U):
         assert rel(o[key], g[key]) < 1.5 * rel(env[key], g[key]) + 2e-2, key
     sign = float(((o["pred_masks"].cpu() > 0) == (g["pred_masks"] > 0)).float().mean())
     env_sign = float(((env["pred_masks"] > 0) == (g["pred_masks"] > 0)).float().mean())
+    record_parity("bf16/transformer_decoder_free_running", pred_logits=rel(o["pred_logits"], g["pred_logits"]),
+                  pred_masks=rel(o["pred_masks"], g["pred_masks"]), mask_sign_agreement=sign,
+                  envelope_pred_logits=rel(env["pred_logits"], g["pred_logits"]), envelope_pred_masks=rel(env["pred_masks"], g["pred_masks"]),
+                  envelope_mask_sign_agreement=env_sign)
     assert sign > env_sign - 0.02 and sign > 0.95, (sign, env_sign)
 
 
@@ -168,6 +180,8 @@ def test_full_model_forward_backward_golden(U):
         loss = T.synthetic_loss(out)
     print("free-running: loss", float(loss), float(g["loss"]), "logits rel", rel(out["pred_logits"], g["pred_logits"]),
           "masks rel", rel(out["pred_masks"], g["pred_masks"]))
+    record_parity("bf16/small_full_model_free_running", loss=float(loss), loss_reference=float(g["loss"]),
+                  pred_logits=rel(out["pred_logits"], g["pred_logits"]), pred_masks=rel(out["pred_masks"], g["pred_masks"]))
     assert abs(float(loss) - float(g["loss"])) < 5e-2 * abs(float(g["loss"]))
     assert rel(out["pred_logits"], g["pred_logits"]) < 0.15
     assert rel(out["pred_masks"], g["pred_masks"]) < 0.15
@@ -198,6 +212,9 @@ def test_full_model_forward_backward_golden(U):
     T.synthetic_loss(oenv).backward()
     named = dict(model.named_parameters())
     bad = []
+    record_parity("bf16/small_full_model_forced_masks", pred_logits=rel(out["pred_logits"], g["pred_logits"]),
+                  pred_masks=rel(out["pred_masks"], g["pred_masks"]), loss=float(loss), loss_reference=float(g["loss"]))
+    gfig = {}
     for i, n in enumerate(g["grad_names"]):
         n = str(n)
         want, stride = g[f"grad{i}"], int(g[f"gradstride{i}"])
@@ -208,8 +225,10 @@ def test_full_model_forward_backward_golden(U):
         cos_e = float(torch.nn.functional.cosine_similarity(ge[::stride], want, dim=0))
         nr, nr_e = float(gr.norm()) / gn, float(ge.norm()) / gn
         print(f"{n:90s} cos {cos:.4f} (envelope {cos_e:.4f})  norm ratio {nr:.4f} (envelope {nr_e:.4f})")
+        gfig[n] = {"cos": cos, "envelope_cos": cos_e, "norm_ratio": nr, "envelope_norm_ratio": nr_e}
         if cos < cos_e - 0.015 or abs(nr - 1) > abs(nr_e - 1) + 0.03:
             bad.append((n, cos, cos_e, nr, nr_e))
+    record_parity("bf16/small_full_model_forced_masks_gradients", **gfig)
     assert not bad, bad
 
 
@@ -240,6 +259,7 @@ def test_full_size_swin_l_properties(U):
         pred.forced_attn_masks = None
     r_logits, r_masks = rel(one["pred_logits"], oref["pred_logits"]), rel(one["pred_masks"], oref["pred_masks"])
     print("full size vs oracle: logits rel", r_logits, "masks rel", r_masks)
+    record_parity("bf16/swin_l_1024x2048_forced_masks", pred_logits=r_logits, pred_masks=r_masks)
     assert r_logits < 3e-2 and r_masks < 3e-2
     # -- determinism: the forward has no atomics, two runs are bitwise equal
     with torch.no_grad():
@@ -252,6 +272,7 @@ def test_full_size_swin_l_properties(U):
         solo, _ = model.forward_features(two[:1])
     r = rel(a["pred_masks"][:1], solo["pred_masks"]), rel(a["pred_logits"][:1], solo["pred_logits"])
     print("batch independence rel", r)
+    record_parity("bf16/swin_l_1024x2048_batch_independence", pred_masks=r[0], pred_logits=r[1])
     assert r[0] < 3e-2 and r[1] < 3e-2
     # -- backward linearity: the gradients of 2 x loss are 2 x the gradients of the loss (a power of two, so every bf16 rounding
     #    scales exactly and only the order of float atomics differs; the masks are detached thresholds of the same forward)
@@ -272,4 +293,56 @@ def test_full_size_swin_l_properties(U):
         assert torch.isfinite(g1[n]).all() and float(g1[n].abs().max()) > 0
         # (not bitwise: atomics order differs run to run, and a 1-ulp fp32 change upstream can flip a bf16 rounding of a gradient
         #  operand downstream; cancellation-heavy sums such as the position-table gradient show that as ~1 % noise)
+        record_parity("bf16/swin_l_1024x2048_backward_linearity", **{n: rel(g2[n], 2.0 * g1[n])})
         assert rel(g2[n], 2.0 * g1[n]) < 3e-2, n
+
+
+def test_predictor_configs0_swin_t_512x1024(U):
+    """BASELINE configs[0] on the HIP path: the DefaultPredictor counterpart (reference demo/defaults.py:51-61, 157-158) built from
+    the reference's shipped Swin-T config chain (resolved values: tests/golden/cfg_cityscapes_swin_t.json, written by
+    oracle/make_cfg_fixture.py), one synthetic 512 x 1024 uint8 image, all three inference heads on.  Checked against the fp32
+    oracle on the same resized image: exact mode tightly, the product's bf16 mode recorded (free-running both)."""
+    import json
+    import os
+    from oracle import fill, postproc_ref as P, torch_ref as T
+    from uenc import ops
+    from uenc.config import add_common_config, add_dinat_config, add_swin_config, add_uni_encoder_config
+    from uenc.d2 import get_cfg
+    from uenc.predictor import DefaultPredictor
+    flat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cfg_cityscapes_swin_t.json")))["cfg"]
+    cfg = get_cfg()
+    add_common_config(cfg); add_swin_config(cfg); add_dinat_config(cfg); add_uni_encoder_config(cfg)
+    opts = []
+    for k, v in flat.items():
+        opts += [k, v]
+    cfg.merge_from_list(opts)
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.WEIGHTS", ""])
+    assert cfg.MODEL.SWIN.DEPTHS == [2, 2, 6, 2] and cfg.INPUT.SEG_MIN_SIZE_TEST == 384
+    g = torch.Generator().manual_seed(11)
+    image = torch.randint(0, 256, (512, 1024, 3), generator=g, dtype=torch.uint8)
+    res = {}
+    for mode in ("bf16", "exact"):
+        ops.set_exact(mode == "exact")
+        try:
+            pred = DefaultPredictor(cfg)
+            _fill(pred.model)
+            out = pred(image, "panoptic")
+            if mode == "bf16":
+                resized = pred._resize(image.permute(2, 0, 1).float())
+                assert tuple(resized.shape[-2:]) == (384, 768)          # ResizeShortestEdge(384, 1024) of a 512 x 1024 image
+                ocfg = T.ModelCfg(swin=T.SWIN_T)
+                sd = fill.state_dict_for(T.model_param_shapes(ocfg))
+                with torch.no_grad():
+                    o = T.oneformer_forward([{"left_image": resized, "task": "The task is panoptic"}], sd, ocfg, upsample=False)
+                    m = P.upsample_and_crop(o["pred_masks"][0], (384, 768), (384, 768), (512, 1024))
+                    sem_ref = P.semantic_inference(o["pred_logits"][0], m)
+            assert out["sem_seg"].shape == (19, 512, 1024) and out["panoptic_seg"][0].shape == (512, 1024)
+            assert out["instances"].pred_classes.numel() <= cfg.TEST.DETECTIONS_PER_IMAGE
+            res[mode] = {"pred_logits": rel(out["pred_logits"], o["pred_logits"][0]), "sem_seg": rel(out["sem_seg"], sem_ref),
+                         "sem_argmax_agreement": float((out["sem_seg"].argmax(0).cpu() == sem_ref.argmax(0)).float().mean())}
+        finally:
+            ops.set_exact(False)
+    record_parity("configs0/predictor_swin_t_512x1024", exact=res["exact"], bf16=res["bf16"])
+    e = res["exact"]
+    assert e["pred_logits"] < 1e-3 and e["sem_seg"] < 1e-3 and e["sem_argmax_agreement"] > 0.999, res
+    assert res["bf16"]["sem_argmax_agreement"] > 0.9, res

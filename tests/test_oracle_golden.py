@@ -119,3 +119,24 @@ def test_model_forward_backward():
         ref = g[f"grad{i}"]
         got = gr[:: int(g[f"gradstride{i}"])]
         assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-7, n
+
+
+def test_transformer_decoder_is_train_contrastive():
+    """`contrastive_logits` of a decoder built with is_train=True is the PRE-loop query tensor
+    (oneformer_transformer_decoder.py:440, 477-480); value and gradients against the reference's own run (fixture F11)."""
+    g, c = load_golden("transformer_decoder"), load_golden("decoder_contrastive")
+    ch = {"res2": 96, "res3": 192, "res4": 384, "res5": 768}
+    sd = {k: v.requires_grad_() for k, v in _sd({k: s for k, s in T.head_param_shapes(T.HeadCfg(), ch).items() if "predictor" in k}).items()}
+    tasks = g["tasks"].clone().requires_grad_()
+    o = T.transformer_decoder([g["ms0"], g["ms1"], g["ms2"]], g["mask_features"], tasks, sd, T.HeadCfg(), is_train=True)
+    cl = o["contrastive_logits"]
+    torch.testing.assert_close(cl, c["contrastive_logits"], atol=1e-4, rtol=1e-4)
+    loss = cl.square().mean() + 0.1 * T.synthetic_loss(o)
+    torch.testing.assert_close(loss, c["loss"], atol=1e-4, rtol=1e-4)
+    loss.backward()
+    p = "sem_seg_head.predictor."
+    for got, key in ((tasks.grad, "grad_tasks"), (sd[p + "query_embed.weight"].grad, "grad_query_embed"),
+                     (sd[p + "class_transformer.decoder.norm.weight"].grad, "grad_class_norm_weight"),
+                     (sd[p + "class_transformer.decoder.layers.1.linear2.bias"].grad, "grad_ct_l1_linear2_bias")):
+        ref = c[key]
+        assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-7, key

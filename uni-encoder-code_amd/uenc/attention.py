@@ -8,13 +8,14 @@ from typing import Optional
 
 import torch
 
+from . import kernels as K
 from .capi import check, lib, stream_ptr
 
 
 def _strided(t: torch.Tensor) -> torch.Tensor:
     """(B, L, E) with unit inner stride and 16-byte aligned rows, copying only if necessary."""
-    if t.dtype != torch.bfloat16:
-        t = t.to(torch.bfloat16)
+    if t.dtype != K.adt():
+        t = t.to(K.adt())
     if t.stride(2) != 1 or t.stride(1) % 8 or t.stride(0) % 8 or t.data_ptr() % 16:
         t = t.contiguous()
     return t
@@ -40,8 +41,17 @@ class MHACoreFn(torch.autograd.Function):
         assert E == nheads * 32, "the HIP attention kernels are built for head_dim 32"
         scale = 32 ** -0.5
         m8, mrs = _mask_bytes(mask)
-        out = torch.empty((B, Lq, E), dtype=torch.bfloat16, device=q.device)
         lse = torch.empty((B, nheads, Lq), dtype=torch.float32, device=q.device)
+        if K.EXACT:                                      # fp32 operands, csrc/exact.hip
+            out = torch.empty((B, Lq, E), dtype=torch.float32, device=q.device)
+            check(lib.uenc_mha_f32_fwd(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                       v.data_ptr(), v.stride(0), v.stride(1), m8.data_ptr() if m8 is not None else 0, mrs,
+                                       out.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr(), B, nheads, Lq, S, scale, stream_ptr()),
+                  "mha_f32_fwd")
+            ctx.save_for_backward(q, k, v, out, lse, m8 if m8 is not None else torch.empty(0, device=q.device))
+            ctx.meta = (nheads, S, scale, mrs, m8 is not None)
+            return out
+        out = torch.empty((B, Lq, E), dtype=torch.bfloat16, device=q.device)
         nws = lib.uenc_mha_fwd_workspace_floats(B, nheads, Lq, S)
         ws = torch.empty((nws,), dtype=torch.float32, device=q.device) if nws else None
         check(lib.uenc_mha_fwd(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
@@ -58,6 +68,19 @@ class MHACoreFn(torch.autograd.Function):
         nheads, S, scale, mrs, has_mask = ctx.meta
         B, Lq, E = q.shape
         dout = _strided(dout)
+        if K.EXACT:
+            dq = torch.empty((B, Lq, E), dtype=torch.float32, device=q.device)
+            dk = torch.zeros((B, S, E), dtype=torch.float32, device=q.device)
+            dv = torch.zeros((B, S, E), dtype=torch.float32, device=q.device)
+            delta = torch.empty((B, nheads, Lq), dtype=torch.float32, device=q.device)
+            check(lib.uenc_mha_f32_bwd(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                       v.data_ptr(), v.stride(0), v.stride(1), m8.data_ptr() if has_mask else 0, mrs,
+                                       out.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr(),
+                                       dout.data_ptr(), dout.stride(0), dout.stride(1),
+                                       dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1),
+                                       dv.data_ptr(), dv.stride(0), dv.stride(1), delta.data_ptr(), B, nheads, Lq, S, scale, stream_ptr()),
+                  "mha_f32_bwd")
+            return dq, dk, dv, None, None
         dq = torch.zeros((B, Lq, E), dtype=torch.float32, device=q.device)
         dk = torch.empty((B, S, E), dtype=torch.bfloat16, device=q.device)
         dv = torch.empty((B, S, E), dtype=torch.bfloat16, device=q.device)

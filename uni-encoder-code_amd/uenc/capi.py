@@ -67,6 +67,14 @@ _SIGNATURES = {
     "uenc_na2d_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_na2d_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_window_attn_bwd_ws_floats": [c_i, c_i, c_i, c_i, c_i],
+    # fp32 exact mode (csrc/exact.hip)
+    "uenc_gemm_nt_f32": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_p],
+    "uenc_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "uenc_window_attn_f32_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_window_attn_f32_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_mha_f32_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_mha_f32_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
+                         c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 }
 

@@ -121,10 +121,23 @@ else:
 
             def _apply_eval(loader, node):
                 # the reference's YAMLs use `!!python/object/apply:eval ["[int(x * 0.1 * 384) for x in range(5, 21)]"]`
-                # (configs/cityscapes/swin/unified_encoder_cityscapes.yaml:40); evaluated as a literal-only expression
+                # (configs/cityscapes/swin/unified_encoder_cityscapes.yaml:40).  Only arithmetic list comprehensions over
+                # int / float / range pass: the syntax tree is checked node by node BEFORE evaluation (empty builtins alone
+                # are no sandbox: attribute walks from a literal reach arbitrary code), anything else is refused.
                 args = loader.construct_sequence(node)
-                return eval(compile(ast.parse(args[0], mode="eval"), "<cfg>", "eval"),
-                            {"__builtins__": {}, "int": int, "range": range, "float": float})
+                tree = ast.parse(args[0], mode="eval")
+                allowed = (ast.Expression, ast.ListComp, ast.comprehension, ast.BinOp, ast.UnaryOp, ast.Add, ast.Sub, ast.Mult,
+                           ast.Div, ast.FloorDiv, ast.Mod, ast.Pow, ast.USub, ast.UAdd, ast.Constant, ast.Name, ast.Load, ast.Store,
+                           ast.Call, ast.List, ast.Tuple)
+                for n in ast.walk(tree):
+                    ok = isinstance(n, allowed)
+                    if isinstance(n, ast.Call):
+                        ok = isinstance(n.func, ast.Name) and n.func.id in ("int", "float", "range") and not n.keywords
+                    if isinstance(n, ast.Constant):
+                        ok = isinstance(n.value, (int, float))
+                    if not ok:
+                        raise ValueError(f"config expression {args[0]!r}: {type(n).__name__} is not allowed")
+                return eval(compile(tree, "<cfg>", "eval"), {"__builtins__": {}, "int": int, "range": range, "float": float})
 
             _Loader.add_constructor("tag:yaml.org,2002:python/object/apply:eval", _apply_eval)
             with open(filename) as f:
@@ -304,8 +317,8 @@ else:
         if isinstance(norm, str):
             if norm == "GN":
                 return nn.GroupNorm(32, out_channels)
-            if norm == "LN":
-                return nn.GroupNorm(1, out_channels)
+            if norm == "LN":     # detectron2's "LN" is a per-pixel channel LayerNorm, NOT GroupNorm(1, C); no shipped config uses it
+                raise NotImplementedError("norm 'LN' (detectron2 channel LayerNorm) is outside the hot path (SURVEY.md §8)")
             raise NotImplementedError(f"norm {norm!r} is outside the hot path (SURVEY.md §8)")
         return norm(out_channels)
 

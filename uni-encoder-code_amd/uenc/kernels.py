@@ -4,6 +4,7 @@ Every wrapper validates what the kernel's grid assumes (device, dtype, inner str
 handing raw pointers to the library; the library re-checks alignment and sizes and refuses
 (-1) rather than launching on a bad shape.
 """
+import os
 from typing import Optional
 
 import torch
@@ -13,6 +14,20 @@ from .capi import BF16, F32, check, dt, lib, ptr, stream_ptr
 
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU = (
     capi.EPI_NONE, capi.EPI_GELU, capi.EPI_RELU, capi.EPI_RESIDUAL, capi.EPI_MUL_DGELU, capi.EPI_MUL_DRELU)
+
+
+# fp32 "exact" arithmetic mode (csrc/exact.hip): every activation that is bf16 between kernels in the
+# product becomes fp32 and every contraction runs on fp32 operands.  A verification mode: UENC_EXACT=1 or ops.set_exact(True).
+EXACT = os.environ.get("UENC_EXACT", "0") == "1"
+
+
+def adt():
+    """dtype of activations handed from kernel to kernel: bf16, or fp32 in exact mode."""
+    return torch.float32 if EXACT else torch.bfloat16
+
+
+def _odt(dtype):
+    return torch.float32 if (EXACT and dtype == torch.bfloat16) else dtype
 
 
 def _mat(t: torch.Tensor, name: str):
@@ -26,6 +41,8 @@ def _mat(t: torch.Tensor, name: str):
 def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 -> bf16 copy (weights).  numel must be a multiple of 8, else falls to the padded path."""
     assert src.dtype == torch.float32 and src.is_contiguous() and src.is_cuda
+    if EXACT:                                   # the "bf16 copy" of an fp32 tensor is the tensor itself
+        return src if out is None else out.copy_(src)
     if out is None:
         out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     n = src.numel()
@@ -40,6 +57,8 @@ def cast_transpose_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -
     """(R, C) fp32 -> (C, R) bf16."""
     assert src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous() and src.is_cuda
     R, C = src.shape
+    if EXACT:                                   # data movement only
+        return src.t().contiguous() if out is None else out.copy_(src.t())
     if out is None:
         out = torch.empty((C, R), dtype=torch.bfloat16, device=src.device)
     assert out.dtype == torch.bfloat16 and tuple(out.shape) == (C, R) and out.is_contiguous()
@@ -55,6 +74,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = 
     _mat(a, "a"); _mat(w, "w")
     M, K = a.shape
     N, K2 = w.shape
+    if EXACT:
+        return _gemm_nt_exact(a, w, bias, epilogue, aux, aux_out, out, alpha, accumulate)
     if K != K2 or w.dtype != torch.bfloat16:
         raise capi.UencError(f"gemm_nt: a {tuple(a.shape)} vs w {tuple(w.shape)} / {w.dtype}")
     if out is None:
@@ -77,12 +98,36 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = 
     return out
 
 
+def _gemm_nt_exact(a, w, bias, epilogue, aux, aux_out, out, alpha, accumulate) -> torch.Tensor:
+    """fp32 operands, fp32 result (uenc_gemm_nt_f32); same epilogues as the bf16 kernels, aux / aux_out fp32."""
+    M, K = a.shape
+    N, K2 = w.shape
+    f32 = torch.float32
+    if K != K2 or a.dtype != f32 or w.dtype != f32:
+        raise capi.UencError(f"gemm_nt (exact): a {tuple(a.shape)} {a.dtype} vs w {tuple(w.shape)} {w.dtype}")
+    if out is None:
+        out = torch.zeros((M, N), dtype=f32, device=a.device) if accumulate else torch.empty((M, N), dtype=f32, device=a.device)
+    _mat(out, "out")
+    assert out.shape == (M, N) and out.dtype == f32
+    for t, name in ((aux, "aux"), (aux_out, "aux_out")):
+        if t is not None:
+            _mat(t, name); assert t.shape == (M, N) and t.dtype == f32
+    if bias is not None:
+        assert bias.dtype == f32 and bias.numel() == N and bias.is_contiguous()
+    check(lib.uenc_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K, ptr(bias),
+                               epilogue, ptr(aux), aux.stride(0) if aux is not None else 0, ptr(aux_out),
+                               aux_out.stride(0) if aux_out is not None else 0, float(alpha), int(accumulate), stream_ptr()), "gemm_nt_f32")
+    return out
+
+
 def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, splitk: int, *, alpha: float = 1.0) -> torch.Tensor:
     """sum_k a[m, k] * w[n, k] in fp32 for a long contraction with few output tiles: `splitk` k-ranges computed by separate
     workgroups, each STORING its partial tile (no atomics), then summed.  a, w bf16 with unit inner stride."""
     _mat(a, "a"); _mat(w, "w")
     M, K = a.shape
     N, K2 = w.shape
+    if EXACT:
+        return _gemm_nt_exact(a, w, None, EPI_NONE, None, None, None, alpha, False)
     if K != K2 or w.dtype != torch.bfloat16:
         raise capi.UencError(f"gemm_nt_splitk: a {tuple(a.shape)} vs w {tuple(w.shape)} / {w.dtype}")
     s = lib.uenc_gemm_nt_splits(K, int(splitk))
@@ -97,6 +142,10 @@ def gemm_nt_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, alph
     One launch; with splitk > 1 / accumulate, out must be fp32 (zeroed by the caller for splitk > 1)."""
     B, M, K = a.shape
     _, N, _ = w.shape
+    if EXACT:
+        for b in range(B):
+            _gemm_nt_exact(a[b], w[b], None, EPI_NONE, None, None, out[b], alpha, accumulate or splitk > 1)
+        return out
     assert a.is_cuda and w.dtype == torch.bfloat16 and w.shape == (B, N, K) and out.shape == (B, M, N)
     assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
     check(lib.uenc_gemm_nt_batched(a.data_ptr(), dt(a), a.stride(1), a.stride(0), w.data_ptr(), w.stride(1), w.stride(0), out.data_ptr(), dt(out),
@@ -114,6 +163,11 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[to
         raise capi.UencError(f"gemm_tn: dy {tuple(dy.shape)} x {tuple(x.shape)} dw {tuple(dw.shape)}")
     if db is not None:
         assert db.dtype == torch.float32 and db.numel() == N and db.is_contiguous()
+    if EXACT:
+        assert dy.dtype == torch.float32 and x.dtype == torch.float32
+        check(lib.uenc_gemm_tn_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), ptr(db), M, N, K,
+                                   stream_ptr()), "gemm_tn_f32")
+        return
     check(lib.uenc_gemm_tn(dy.data_ptr(), dt(dy), dy.stride(0), x.data_ptr(), dt(x), x.stride(0), dw.data_ptr(), dw.stride(0),
                            ptr(db), M, N, K, int(splitm), stream_ptr()), "gemm_tn")
 
@@ -126,6 +180,11 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, r
     C = x.shape[-1]
     assert x.is_cuda and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     M = x.numel() // C
+    out_dtype = _odt(out_dtype)
+    if EXACT and twin is not None:
+        twin_exact, twin = twin, None           # the operand copy of an fp32 y is y itself
+    else:
+        twin_exact = None
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     h = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_h else None
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if want_stats else None
@@ -138,6 +197,8 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, r
     check(lib.uenc_layernorm_fwd(x.data_ptr(), dt(x), ptr(res), dt(res) if res is not None else 0, ptr(h),
                                  gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), dt(y), ptr(stats), M, C, float(eps),
                                  ptr(y16), stream_ptr()), "layernorm_fwd")
+    if twin_exact is not None and out_dtype == torch.float32:
+        twin_exact.append(y)
     return y, h, stats
 
 
@@ -149,6 +210,10 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
     C = h.shape[-1]
     M = h.numel() // C
     assert dy.is_contiguous() and h.is_contiguous() and dy.shape == h.shape
+    dx_dtype = _odt(dx_dtype)
+    twin_exact = None
+    if EXACT and twin is not None:
+        twin_exact, twin = twin, None
     dx = torch.empty(h.shape, dtype=dx_dtype, device=h.device)
     if dres is not None:
         assert dres.dtype == torch.float32 and dres.is_contiguous() and dres.shape == h.shape
@@ -160,6 +225,8 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
     check(lib.uenc_layernorm_bwd(dy.data_ptr(), dt(dy), h.data_ptr(), dt(h), stats.data_ptr(), gamma.data_ptr(),
                                  ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, ptr(dx16), ptr(part), stream_ptr()),
           "layernorm_bwd")
+    if twin_exact is not None and dx_dtype == torch.float32:
+        twin_exact.append(dx)
     return dx
 
 
@@ -220,6 +287,8 @@ def na2d_fwd(qkv: torch.Tensor, rpb: Optional[torch.Tensor], nH: int, ks: int, d
     """Neighbourhood attention on qkv (B, H, W, 3C) bf16 (C = nH * 32) -> out (B, H, W, C) bf16, lse (B, nH, H, W) fp32."""
     B, H, W, C3 = qkv.shape
     C = C3 // 3
+    if EXACT:
+        raise NotImplementedError("the fp32 exact mode covers the Swin path; neighbourhood attention has no fp32 kernel")
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and C == nH * 32, "na2d: head_dim must be 32"
     if rpb is not None:
         assert rpb.dtype == torch.float32 and rpb.is_contiguous() and tuple(rpb.shape) == (nH, 2 * ks - 1, 2 * ks - 1)
@@ -266,6 +335,8 @@ def patch_merge_ln_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, g
 def relpos_expand(table: torch.Tensor, ws: int):
     """relative_position_bias_table ((2ws-1)^2, nH) fp32 -> dense (nH, NP, NP) in query-major and key-major order."""
     assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] == (2 * ws - 1) ** 2
+    if EXACT:                                   # the fp32 window-attention kernels index the table themselves
+        return table, table
     nH = table.shape[1]
     NP = lib.uenc_window_attn_np(ws)
     bq = torch.empty((nH, NP, NP), dtype=torch.float32, device=table.device)
@@ -279,6 +350,13 @@ def window_attn_fwd(qkv: torch.Tensor, qkv_bias16: torch.Tensor, bias_q: torch.T
     """qkv (B, H, W, 3C) bf16 -> attention output (B, H, W, C) bf16 (before proj).  head_dim is 32."""
     B, H, W, C3 = qkv.shape
     C = C3 // 3
+    if EXACT:                                   # qkv / bias fp32, bias_q = the raw relative-position table ((2ws-1)^2, nH)
+        assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv_bias16.dtype == torch.float32 and qkv_bias16.numel() == C3
+        assert bias_q.dtype == torch.float32 and tuple(bias_q.shape) == ((2 * ws - 1) ** 2, C // 32) and bias_q.is_contiguous()
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=qkv.device)
+        check(lib.uenc_window_attn_f32_fwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), out.data_ptr(), B, H, W, C, C // 32, ws,
+                                           shift, float(scale), stream_ptr()), "window_attn_f32_fwd")
+        return out
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv_bias16.dtype == torch.bfloat16
     assert qkv_bias16.numel() == C3 and C % 32 == 0 and bias_q.shape[0] == C // 32
     out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=qkv.device)
@@ -306,6 +384,16 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
     B, H, W, C3 = qkv.shape
     C = C3 // 3
     nH = C // 32
+    if EXACT:
+        assert qkv.dtype == torch.float32 and d_out.dtype == torch.float32 and d_out.is_contiguous() and d_out.shape == (B, H, W, C)
+        TT = (2 * ws - 1) ** 2
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.zeros((TT, nH), dtype=torch.float32, device=qkv.device)
+        dpad = torch.zeros((3 * C,), dtype=torch.float32, device=qkv.device)
+        check(lib.uenc_window_attn_f32_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(),
+                                           dtable.data_ptr(), dpad.data_ptr(), B, H, W, C, nH, ws, shift, float(scale), stream_ptr()),
+              "window_attn_f32_bwd")
+        return dqkv, dtable.t(), dpad
     assert d_out.dtype == torch.bfloat16 and d_out.is_contiguous() and d_out.shape == (B, H, W, C)
     assert o_saved.dtype == torch.bfloat16 and o_saved.is_contiguous()
     dqkv = torch.empty_like(qkv)
@@ -331,7 +419,7 @@ def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.flo
             raise capi.UencError("msdeform_attn: tensors must be contiguous CUDA tensors")
     assert shapes.dtype == torch.int64 and level_start.dtype == torch.int64
     assert loc.dtype == torch.float32 and attn.dtype == torch.float32 and attn.shape == (B, Lq, M, L, P)
-    out = torch.empty((B, Lq, M * D), dtype=out_dtype, device=value.device)
+    out = torch.empty((B, Lq, M * D), dtype=_odt(out_dtype), device=value.device)
     check(lib.uenc_msdeform_attn_fwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(),
                                      attn.data_ptr(), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, stream_ptr()),
           "msdeform_attn_fwd")
@@ -398,7 +486,7 @@ def groupnorm_tokens_fwd(x, gamma, beta, G: int, eps: float, *, relu=False, add_
     bilinear resize to add_hw = (H, W)."""
     B, HW, C = x.shape
     assert x.is_cuda and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
-    y = torch.empty((B, HW, C), dtype=out_dtype, device=x.device)
+    y = torch.empty((B, HW, C), dtype=_odt(out_dtype), device=x.device)
     stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
     scratch = _scratch("gn", int(lib.uenc_groupnorm_tokens_scratch_bytes(B, HW, C, G)), x.device)
     Hs = Ws = H = W = 0
@@ -415,7 +503,7 @@ def groupnorm_tokens_fwd(x, gamma, beta, G: int, eps: float, *, relu=False, add_
 def groupnorm_tokens_bwd(dy, x, gamma, beta, stats, G: int, *, relu=False, dgamma=None, dbeta=None, dx_dtype=torch.bfloat16):
     B, HW, C = x.shape
     assert dy.is_contiguous() and dy.shape == x.shape and x.is_contiguous()
-    dx = torch.empty((B, HW, C), dtype=dx_dtype, device=x.device)
+    dx = torch.empty((B, HW, C), dtype=_odt(dx_dtype), device=x.device)
     scratch = _scratch("gn", int(lib.uenc_groupnorm_tokens_scratch_bytes(B, HW, C, G)), x.device)
     check(lib.uenc_groupnorm_tokens_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
                                         dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), scratch.data_ptr(), B, HW, C, G, int(relu),
@@ -436,6 +524,9 @@ def upsample_bilinear_tokens_bwd(dy, Hs: int, Ws: int):
 def im2col3x3(x16):
     """(B, H, W, C) bf16 -> (B*H*W, 9*C) bf16 patch matrix, column order (ky, kx, c)."""
     B, H, W, C = x16.shape
+    if EXACT and x16.dtype == torch.float32:
+        # pure data movement: gather the fp32 map as a bf16 map with twice the channels (same bytes, same (ky, kx, c) column order)
+        return im2col3x3(x16.contiguous().view(torch.bfloat16)).view(torch.float32)
     assert x16.dtype == torch.bfloat16 and x16.is_contiguous()
     col = torch.empty((B * H * W, 9 * C), dtype=torch.bfloat16, device=x16.device)
     check(lib.uenc_im2col3x3(x16.data_ptr(), col.data_ptr(), B, H, W, C, stream_ptr()), "im2col3x3")
@@ -443,6 +534,13 @@ def im2col3x3(x16):
 
 
 def col2im3x3(dcol, B: int, H: int, W: int, C: int):
+    if EXACT and dcol.dtype == torch.float32:   # adjoint of the gather as nine shifted fp32 adds (verification mode only)
+        d = dcol.view(B, H, W, 9, C)
+        dxp = dcol.new_zeros((B, H + 2, W + 2, C))
+        for t in range(9):
+            ky, kx = divmod(t, 3)
+            dxp[:, ky:ky + H, kx:kx + W] += d[:, :, :, t]
+        return dxp[:, 1:1 + H, 1:1 + W].contiguous()
     assert dcol.dtype == torch.bfloat16 and dcol.is_contiguous() and dcol.numel() == B * H * W * 9 * C
     dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dcol.device)
     check(lib.uenc_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "col2im3x3")
@@ -455,6 +553,8 @@ def col2im3x3(dcol, B: int, H: int, W: int, C: int):
 def add_cast_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """bf16(a + b); b may be one period of a (e.g. (S, C) against (B, S, C))."""
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    if EXACT:
+        return (a.view(-1, b.numel()) + b.view(1, -1)).view(a.shape)
     out = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
     check(lib.uenc_add_cast_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), b.numel(), stream_ptr()), "add_cast_bf16")
     return out
@@ -474,6 +574,12 @@ def msda_prep_bwd(dloc, daw, aw, shapes, ncols: int):
     """-> d(offaw) (B*Lq, ncols) bf16."""
     B, Lq, M, L, P, _ = dloc.shape
     assert dloc.is_contiguous() and daw.is_contiguous() and aw.is_contiguous() and ncols == 3 * M * L * P
+    if EXACT:   # fp32 result: d(offset) = d(loc) / (W_l, H_l); d(logit) = aw * (d(aw) - sum_{l,p} aw * d(aw))   (elementwise glue)
+        norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(torch.float32).view(1, 1, 1, L, 1, 2)
+        doff = (dloc / norm).reshape(B * Lq, 2 * M * L * P)
+        a, g = aw.view(B * Lq, M, L * P), daw.view(B * Lq, M, L * P)
+        dlog = (a * (g - (a * g).sum(-1, keepdim=True))).reshape(B * Lq, M * L * P)
+        return torch.cat([doff, dlog], 1).contiguous()
     out = torch.empty((B * Lq, ncols), dtype=torch.bfloat16, device=dloc.device)
     check(lib.uenc_msda_prep_bwd(dloc.data_ptr(), daw.data_ptr(), aw.data_ptr(), shapes.data_ptr(), out.data_ptr(), ncols, B * Lq, Lq,
                                  M, L, P, stream_ptr()), "msda_prep_bwd")
@@ -482,6 +588,10 @@ def msda_prep_bwd(dloc, daw, aw, shapes, ncols: int):
 
 def segment_colsum(x16: torch.Tensor, seg_start: torch.Tensor, rows_per_image: int, images: int) -> torch.Tensor:
     """x16 (images * rows_per_image, cols) bf16 -> (nseg, cols) fp32 sums over the row segments of every image."""
+    if EXACT:
+        st = seg_start.tolist() + [rows_per_image]
+        xv = x16.view(images, rows_per_image, -1)
+        return torch.stack([xv[:, st[i]:st[i + 1]].sum((0, 1)) for i in range(len(st) - 1)])
     assert x16.dtype == torch.bfloat16 and x16.stride(1) == 1 and seg_start.dtype == torch.int64
     nseg, cols = seg_start.numel(), x16.shape[1]
     out = torch.empty((nseg, 128, cols), dtype=torch.float32, device=x16.device)          # 128 stored block partials per segment

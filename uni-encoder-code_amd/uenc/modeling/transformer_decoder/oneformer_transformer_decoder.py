@@ -282,11 +282,12 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         tgt = t_tok.expand(-1, Q - 1, -1) if self.use_task_norm else torch.zeros_like(qe[:, :-1])
         out_t = self.class_transformer(mem, key_in, qe[:, :-1], tgt)
         output = torch.cat([out_t, t_tok], 1)
+        query_class = output                                 # reference :440, 477-478: the PRE-loop queries (batch-first here)
 
-        mf16 = mf32.detach().to(torch.bfloat16)
+        mf16 = mf32.detach().to(K.adt())
         # (B, C, HW) bf16 operand of the mask-embedding gradient GEMM: LDS-tiled cast + transpose per image (a strided ATen copy of the
         # 134 MB map took 0.28 ms)
-        mf16_chw = torch.empty((B, mf32.shape[2], mf32.shape[1]), dtype=torch.bfloat16, device=mf32.device)
+        mf16_chw = torch.empty((B, mf32.shape[2], mf32.shape[1]), dtype=K.adt(), device=mf32.device)
         for b in range(B):
             K.cast_transpose_bf16(mf32[b].detach(), out=mf16_chw[b])
         mes = []                                             # mask embeddings of all heads: their einsums share one autograd node
@@ -308,7 +309,7 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         assert len(predictions_class) == self.num_layers + 1
         # the eager mask logits become differentiable here: one node for all heads (ops.MaskHeadsFn)
         predictions_mask = [m.view(B, -1, H4, W4) for m in ops.mask_heads(mf32, mf16_chw, [m.view(B, -1, H4 * W4) for m in predictions_mask], mes)]
-        return {"contrastive_logits": output if self.is_train else None,
+        return {"contrastive_logits": query_class if self.is_train else None,
                 "pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1],
                 "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(predictions_class[:-1], predictions_mask[:-1])]}
 

@@ -67,7 +67,7 @@ class ParamCache:
         def make():
             ww = w if aligned else torch.nn.functional.pad(w, (0, -Kd % 8, 0, -N % 8))
             return K.cast_bf16(ww.contiguous())
-        plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 0) if aligned else None
+        plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 0) if (aligned and not K.EXACT) else None
         return self._get(p, ("m", rows), make, plan)
 
     def mat_t(self, p: torch.Tensor, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -79,7 +79,7 @@ class ParamCache:
         def make():
             ww = w if aligned else torch.nn.functional.pad(w, (0, -Kd % 8, 0, -N % 8))
             return K.cast_transpose_bf16(ww.contiguous())
-        plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 1) if aligned else None
+        plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 1) if (aligned and not K.EXACT) else None
         return self._get(p, ("t", rows), make, plan)
 
     def _get2(self, p1, p2, kind, make):
@@ -107,7 +107,7 @@ class ParamCache:
         return self._get2(p1, p2, "catv", lambda: torch.cat([p1.detach(), p2.detach()]).float().contiguous())
 
     def vec16(self, p: torch.Tensor) -> torch.Tensor:
-        return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()), (0, 1, p.numel(), 0))
+        return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()), None if K.EXACT else (0, 1, p.numel(), 0))
 
     def refresh(self):
         """Re-cast every cached operand copy from its (updated) fp32 master, in one launch."""
@@ -141,6 +141,18 @@ class ParamCache:
 
 
 CACHE = ParamCache()
+
+
+def set_exact(flag: bool):
+    """Switch the fp32 "exact" arithmetic mode (csrc/exact.hip) on or off for everything launched afterwards: fp32 operands and
+    activations end to end.  A verification mode -- the product's mode is bf16 MFMA operands."""
+    K.EXACT = bool(flag)
+    CACHE.invalidate()
+    _TWINS.clear()
+
+
+def is_exact() -> bool:
+    return K.EXACT
 
 
 _GRAD_LISTENER = None
@@ -338,10 +350,10 @@ def _tn_notify(*params):
 
 def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor], notify=()):
     """gw += dy^T x, gb += column sums of dy: deferred to a grouped launch when the operands allow it."""
-    if WGRADS.enabled and WGRADS.eligible(dy, x, gw):
+    if WGRADS.enabled and not K.EXACT and WGRADS.eligible(dy, x, gw):
         WGRADS.add(dy, x, gw, gb, notify)
         return
-    if WGRADS.enabled and WGRADS.eligible_small(dy, x, gw):
+    if WGRADS.enabled and not K.EXACT and WGRADS.eligible_small(dy, x, gw):
         WGRADS.add_small(dy, x, gw, gb, notify)
         return
     K.gemm_tn(dy, x, gw, gb)
@@ -362,6 +374,8 @@ _TWINS = {}
 
 
 def _register_twin(t32: torch.Tensor, t16: torch.Tensor):
+    if t16 is t32 or K.EXACT:               # exact mode: an fp32 tensor is its own operand copy (and must not keep itself alive here)
+        return
     key = t32.data_ptr()
 
     def _gone(_, key=key):
@@ -497,7 +511,7 @@ class MLPFn(torch.autograd.Function):
             w, b = params[2 * i], params[2 * i + 1]
             if i < n - 1:
                 if act == "gelu":
-                    pre = torch.empty((h.shape[0], w.shape[0]), dtype=BF16, device=h.device)
+                    pre = torch.empty((h.shape[0], w.shape[0]), dtype=K.adt(), device=h.device)
                     h = _fwd_gemm(h, w, b, None, epilogue=K.EPI_GELU, aux_out=pre)
                     pres.append(pre)
                 else:
@@ -614,7 +628,7 @@ def _scaled_rows(g16, scales):
         return g16
     B = len(scales)
     sc = torch.tensor(scales, dtype=torch.float32).to(g16.device, non_blocking=True)
-    return (g16.view(B, -1, g16.shape[-1]).float() * sc.view(B, 1, 1)).to(BF16).view(g16.shape)
+    return (g16.view(B, -1, g16.shape[-1]).float() * sc.view(B, 1, 1)).to(K.adt()).view(g16.shape)
 
 
 class SwinBlockFn(torch.autograd.Function):
@@ -636,7 +650,7 @@ class SwinBlockFn(torch.autograd.Function):
         attn = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, ws, shift, scale)
         x1 = _branch_gemm(attn.view(M, C), CACHE.mat(wproj), bproj.detach(), x2, C, s1)
         xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
-        pre = torch.empty((M, w1.shape[0]), dtype=BF16, device=x.device)
+        pre = torch.empty((M, w1.shape[0]), dtype=K.adt(), device=x.device)
         h = K.gemm_nt(xn2, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_GELU, aux_out=pre)
         x2o = _branch_gemm(h, CACHE.mat(w2), bb2.detach(), x1, C, s2)
         ctx.dp = (s1, s2)
@@ -877,8 +891,8 @@ class MaskHeadsFn(torch.autograd.Function):
         n, Q = len(mes), mes[0].shape[1]
         Mp = -(-(n * Q) // 64) * 64
         dev = mf16_chw.device
-        D = torch.empty((B, Mp, HW), dtype=BF16, device=dev)          # stacked gradient rows of all heads
-        ME = torch.zeros((B, Mp, C), dtype=BF16, device=dev)
+        D = torch.empty((B, Mp, HW), dtype=K.adt(), device=dev)       # stacked gradient rows of all heads
+        ME = torch.zeros((B, Mp, C), dtype=K.adt(), device=dev)
         for h, (d, me) in enumerate(zip(douts, mes)):
             r = h * Q
             if d is None:
@@ -897,7 +911,11 @@ class MaskHeadsFn(torch.autograd.Function):
         dme = [K.gemm_nt_splitk(D[b], mf16_chw[b], split) for b in range(B)]
         # d(mask features): contraction over the stacked rows, one stored GEMM per image
         dmf = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and K.EXACT:
+            dmf = torch.zeros((B, HW, C), dtype=F32, device=dev)
+            for b in range(B):
+                K.gemm_tn(D[b], ME[b], dmf[b], None)
+        elif ctx.needs_input_grad[0]:
             dmf = torch.empty((B, HW, C), dtype=F32, device=dev)
             tile = 256 if C % 256 == 0 else 128
             tiles_k = -(-C // tile)
@@ -983,7 +1001,7 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         B, H, W, C = x.shape
-        x16 = x if x.dtype == BF16 else x.to(BF16)
+        x16 = x if x.dtype == K.adt() else x.to(K.adt())
         col = K.im2col3x3(x16 if x16.is_contiguous() else x16.contiguous())
         out = K.gemm_nt(col, Conv3x3Fn._wmat(weight), out_dtype=F32)
         ctx.save_for_backward(col, weight)
@@ -1004,12 +1022,12 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dcol = K.gemm_nt(dy2, Conv3x3Fn._wmat_t(weight))                                  # (M, 9*Cin) bf16
             dx = K.col2im3x3(dcol, B, H, W, C)
-            if ctx.in_dtype != BF16:
+            if ctx.in_dtype != dx.dtype:
                 dx = dx.to(ctx.in_dtype)
         if weight.requires_grad:
             M = B * H * W
             dw = torch.zeros((Co, 9 * C), dtype=F32, device=dy.device)
-            if M % 64 == 0 and Co % 8 == 0:
+            if M % 64 == 0 and Co % 8 == 0 and not K.EXACT:
                 tile = 256 if Co % 256 == 0 else 128
                 nsplit = max(1, M // 16384)
                 mlen = -(-(M // 64) // nsplit) * 64
