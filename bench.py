@@ -11,17 +11,29 @@ forward of backbone + pixel decoder + transformer decoder + the final x4 mask up
 (reference model/oneformer_model.py:244-263), the synthetic deep-supervision loss of SURVEY.md §8d,
 backward, and (N > 1) the bucketed RCCL gradient all-reduce.  Rank 0 prints ONE JSON line.
 The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the reported time
-is the MAX over ranks; `value` = images all ranks processed / that time.
+is the MAX over ranks; `value` = images all ranks processed / that time.  The headline runs the model in eval() mode
+(deterministic, the full FLOPs of every residual branch); the training-mode step (DropPath / dropout on) is timed as
+well and reported under `train_mode`.
 
-`roofline`: the dominant kernel family (bf16 MFMA GEMM) timed per launch with HIP events on its launch
-stream (`uenc_prof_*`) over a repetition of the timed steps, algorithmic FLOPs = 2*M*N*K per launch.
-`cpu_baseline`: the fp32 oracle (oracle/torch_ref.py, a "port") forward+backward on the host cores, on a
-bounded sample (one image at reduced resolution), converted to the metric's unit by pixel count.
+Extra keys of the line (all measured in this run; rank 0, N = 1 only, after the timed region):
+  `step_ms`            per-iteration device time of the timed steps (HIP events): median / min / max
+  `host_enqueue_ms`    host time to enqueue one step from an idle stream (launch-bound if >= ms_per_step)
+  `forward_only`       inference forward (no_grad, incl. the mask upsample) img/s
+  `train_mode`         the same step with model.train(): stochastic depth + the decoders' dropout active
+  `gpu_eager_baseline` oracle/torch_ref.py fp32 forward on the SAME GPU through ATen ("reference PyTorch-ROCm path" of
+                       BASELINE.json's north_star; a baseline, not the product) and the product's forward speed-up over it
+  `roofline`           dominant kernel family (bf16 MFMA GEMM) timed per launch with HIP events on its launch stream
+                       (`uenc_prof_*`) over a repetition of the timed steps; algorithmic FLOPs = 2*M*N*K per launch;
+                       per-family algorithmic bytes; `traffic` from the committed rocprofv3 PMC summary when it was
+                       measured on the current kernel sources (else null)
+  `cpu_baseline`       the fp32 oracle (a "port") forward+backward of ONE full-size 1024x2048 image on the host cores
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -38,6 +50,7 @@ H_IMG, W_IMG, PER_GPU_BATCH = 1024, 2048, 2
 SWIN_L = dict(EMBED_DIM=192, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[6, 12, 24, 48], WINDOW_SIZE=12)
 # forward FLOPs per image of the workload: backbone 3109.3 GF + head 866.6 GF; fwd+bwd = 3x
 GFLOP_FWD_PER_IMG = 3976.0
+PROFILE_ROUND = "r02"
 
 
 # BASELINE configs[4] (not the headline): UENC_BENCH_BACKBONE=dinat swaps the backbone for DiNAT-L (kernel 7; dilations = 1 / the largest
@@ -95,15 +108,20 @@ def synthetic_loss(out):
     return loss
 
 
-def cpu_baseline(budget_h=256, budget_w=512):
-    """fp32 oracle forward+backward of the same Swin-L model on one (budget_h x budget_w) image on the host cores."""
-    from oracle import fill, torch_ref as T
+def _cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)       # a 1-GPU box grants 16 CPUs whatever the host has: more threads only oversubscribe them
+    return min(cores, 16)        # a 1-GPU box grants 16 CPUs whatever the host has: more threads only oversubscribe them
+
+
+def cpu_baseline():
+    """fp32 oracle forward+backward of the same Swin-L model on ONE full-size 1024 x 2048 image on the host cores (no
+    extrapolation: the sample is one unit of the metric's own workload; ~30-60 s)."""
+    from oracle import fill, torch_ref as T
+    cores = _cores()
     torch.set_num_threads(cores)
     cfg = T.ModelCfg(swin=T.SWIN_L)
     sd = {k: v.requires_grad_() for k, v in fill.state_dict_for(T.model_param_shapes(cfg)).items()}
@@ -116,15 +134,98 @@ def cpu_baseline(budget_h=256, budget_w=512):
         out = T.oneformer_forward([{"left_image": img, "task": "The task is panoptic"}], sd, cfg, upsample=True)
         T.synthetic_loss(out).backward()
 
-    print(f"[bench] cpu_baseline: oracle on {cores} threads ...", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: oracle on {cores} threads, one {H_IMG}x{W_IMG} image ...", file=sys.stderr, flush=True)
     step(96, 192)                # warm-up (allocator, thread pool) on a small image
     t0 = time.perf_counter()
-    step(budget_h, budget_w)
+    step(H_IMG, W_IMG)
     dt = time.perf_counter() - t0
-    frac = (budget_h * budget_w) / float(H_IMG * W_IMG)
-    return {"value": round(frac / dt, 5), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_ref.py fp32 fwd+bwd, full Swin-L OneFormer, 1 image {budget_h}x{budget_w} "
-                      f"({dt:.1f} s), scaled by pixel count x{1 / frac:.0f} to 1024x2048"}
+    return {"value": round(1.0 / dt, 5), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_ref.py fp32 fwd+bwd (incl. the x4 mask upsample), full Swin-L OneFormer, ONE image {H_IMG}x{W_IMG} "
+                      f"in {dt:.1f} s on {cores} threads (bs 1 of the metric's bs 2; no extrapolation)"}
+
+
+def gpu_eager_baseline(device, steps=2):
+    """The fp32 oracle's FORWARD on this GPU through ATen (eager PyTorch-ROCm): the "reference PyTorch path" of north_star's >= 3x
+    target, bs 2 at 1024 x 2048, including the x4 mask upsample.  A baseline, never the product."""
+    from oracle import fill, torch_ref as T
+    cfg = T.ModelCfg(swin=T.SWIN_L)
+    sd = {k: v.to(device) for k, v in fill.state_dict_for(T.model_param_shapes(cfg)).items()}
+    g = torch.Generator().manual_seed(1000)
+    imgs = [torch.randint(0, 256, (3, H_IMG, W_IMG), generator=g).float().to(device) for _ in range(PER_GPU_BATCH)]
+    batch = [{"left_image": im, "task": "The task is panoptic"} for im in imgs]
+
+    def fwd():
+        with torch.no_grad(), torch.device(device):
+            return T.oneformer_forward(batch, sd, cfg, upsample=True)
+    fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fwd()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(PER_GPU_BATCH / dt, 3), "unit": "img/s (forward only)", "ms_per_forward": round(dt * 1e3, 1),
+            "what": "oracle/torch_ref.py (fp32, eager ATen ops on this GPU), bs 2 1024x2048, forward + mask upsample"}
+
+
+def _kernel_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "uni-encoder-code_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h")):
+            with open(os.path.join(d, n), "rb") as f:
+                h.update(n.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _quoted_profile(name):
+    """A committed rocprofv3 summary (profiles/<round>_<name>.json) is quoted only if it was measured on the kernel sources
+    this run executes (`kernel_sources_sha` recorded by the tool that wrote it); otherwise None, never a stale constant."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")) as f:
+            d = json.load(f)
+        return d if d.get("kernel_sources_sha") == _kernel_sources_sha() else None
+    except Exception:
+        return None
+
+
+def dp_check(model, buckets, batches, step_fn, rank, world, device):
+    """N > 1 correctness of the real model's data-parallel path: the all-reduced gradients of one step (every rank on its own
+    batch) against the mean of `world` single-rank backward passes on the same batches, computed locally by every rank."""
+    from uenc import ops
+    step_fn(batches[rank])
+    torch.cuda.synchronize()
+    reduced = buckets.flat.clone()
+    saved_world = buckets.world
+    buckets.world = 1                                  # local passes: no collective, no averaging
+    acc = torch.zeros_like(reduced)
+    for r in range(world):
+        step_fn(batches[r])
+        acc += buckets.flat
+    acc /= world
+    step_fn(batches[0]); a = buckets.flat.clone()
+    step_fn(batches[0]); b = buckets.flat.clone()      # run-to-run noise floor (float atomics order)
+    buckets.world = saved_world
+    torch.cuda.synchronize()
+    per = []
+    for i, v in buckets._views.items():
+        s = v.data_ptr() - buckets.flat.data_ptr()
+        s //= 4
+        n = v.numel()
+        ref = acc[s:s + n]
+        den = float(ref.norm()) + 1e-30
+        per.append((float((reduced[s:s + n] - ref).norm()) / den, float((a[s:s + n] - b[s:s + n]).norm()) / (float(a[s:s + n].norm()) + 1e-30), i))
+    names = {id(p): n for n, p in model.named_parameters()}
+    worst = sorted(per, reverse=True)[:5]
+    rec = {"world": world, "rank": rank, "parameters_reduced": len(per), "buckets": len(buckets.bucket_ranges),
+           "flat_mb": round(buckets.flat.numel() * 4 / 2 ** 20, 1),
+           "global_rel": float((reduced - acc).norm() / acc.norm()), "global_run_to_run_rel": float((a - b).norm() / a.norm()),
+           "max_param_rel": worst[0][0], "median_param_rel": statistics.median(x[0] for x in per),
+           "max_param_run_to_run_rel": max(x[1] for x in per),
+           "worst": [{"param": names.get(id(buckets.params[i]), str(i)), "rel": r, "run_to_run_rel": rr} for r, rr, i in worst],
+           "what": "all-reduced gradients of one DP step vs the mean of `world` single-rank passes on the same batches; "
+                   "differences = float-atomics order (see run_to_run_rel: two identical local passes)"}
+    return rec
 
 
 def main():
@@ -133,7 +234,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip forward-only / train-mode / eager-baseline legs (profiling runs)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--check-dp", default="", help="N > 1: verify the reduced gradients against single-rank passes, write this JSON")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,19 +259,22 @@ def main():
     from uenc.d2 import build_model
     from uenc.dp import GradBuckets
 
-    torch.manual_seed(0)                       # identical replicas
+    torch.manual_seed(0)                       # identical replicas (GradBuckets also broadcasts rank 0's parameters)
     model = build_model(make_cfg(device))
-    model.eval()                               # deterministic path: dropout / stochastic depth = identity (same FLOPs)
+    model.eval()                               # deterministic path: dropout / stochastic depth = identity (the full FLOPs)
     buckets = GradBuckets(model, bucket_mb=args.bucket_mb)
-    g = torch.Generator().manual_seed(1000 + rank)
-    batch = [{"left_image": torch.randint(0, 256, (3, H_IMG, W_IMG), generator=g).float().to(device),
-              "task": "The task is panoptic", "type": "segmentation", "height": H_IMG, "width": W_IMG}
-             for _ in range(PER_GPU_BATCH)]
 
-    def step():
+    def make_batch(r):
+        g = torch.Generator().manual_seed(1000 + r)
+        return [{"left_image": torch.randint(0, 256, (3, H_IMG, W_IMG), generator=g).float().to(device),
+                 "task": "The task is panoptic", "type": "segmentation", "height": H_IMG, "width": W_IMG}
+                for _ in range(PER_GPU_BATCH)]
+    batch = make_batch(rank)
+
+    def step(b=None):
         buckets.zero_grad()
         ops.CACHE.refresh()                    # weights change every training step: every bf16 operand copy is re-cast
-        out, images = model.forward_features(batch)
+        out, images = model.forward_features(b if b is not None else batch)
         with torch.no_grad():                  # reference :255-263, part of the forward it times
             model.upsample_masks(out["pred_masks"], images.tensor.shape[-2:])
         loss = synthetic_loss(out)
@@ -184,13 +290,20 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     sync()
-    # No HIP graph: the step is GPU-bound -- the host enqueues its ~2000 launches in ~50 ms, the GPU needs ~80 (tools/
-    # cpu_bound_probe.py) -- so replaying a captured graph would not shorten it.
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        evs[i][0].record()
         loss = step()
+        evs[i][1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = [a.elapsed_time(b) for a, b in evs]
+    # host cost of one step, enqueued into an idle stream (the GPU is behind the host for the whole call)
+    t1 = time.perf_counter()
+    step()
+    host_ms = (time.perf_counter() - t1) * 1e3
+    sync()
     # per-launch timing of the GEMM families: HIP events recorded on the launch stream around every launch, over a repetition
     # of the same K steps -- inside the timed region the ~1200 event pairs per step cost 4 % of `value` (measured: 23.4 vs
     # 24.4 img/s), so the timed region itself stays un-instrumented
@@ -212,6 +325,52 @@ def main():
         alg_bytes[name] = by.value
     capi.lib.uenc_prof_enable(0)
 
+    dp_rec = None
+    if world > 1 and args.check_dp:
+        dp_rec = dp_check(model, buckets, [make_batch(r) for r in range(world)], step, rank, world, device)
+
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # forward only (inference): no_grad, incl. the x4 mask upsample
+        def fwd():
+            with torch.no_grad():
+                out, images = model.forward_features(batch)
+                model.upsample_masks(out["pred_masks"], images.tensor.shape[-2:])
+        for _ in range(2):
+            fwd()
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        nf = max(4, args.steps)
+        for _ in range(nf):
+            fwd()
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - tf) / nf
+        extras["forward_only"] = {"value": round(PER_GPU_BATCH / tf, 3), "unit": "img/s", "ms_per_forward": round(tf * 1e3, 3)}
+        # training mode: stochastic depth (Swin DropPath 0..0.3), dropout 0.1 of the deformable encoder and the class transformer
+        model.train()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        nt = max(4, args.steps)
+        for _ in range(nt):
+            step()
+        torch.cuda.synchronize()
+        tt = (time.perf_counter() - tt) / nt
+        model.eval()
+        extras["train_mode"] = {"ms_per_step": round(tt * 1e3, 3), "value": round(PER_GPU_BATCH / tt, 3), "unit": "img/s",
+                                "what": "model.train(): DropPath (dropped residual branches of a sample are skipped, kept ones scaled), "
+                                        "dropout 0.1 in the deformable encoder layers and the class transformer"}
+        try:
+            del loss
+            buckets.zero_grad()
+            torch.cuda.empty_cache()
+            eb = gpu_eager_baseline(device)
+            eb["product_forward_speedup"] = round(extras["forward_only"]["value"] / eb["value"], 2)
+            extras["gpu_eager_baseline"] = eb
+        except Exception as e:                      # e.g. out of memory beside the product's buffers: report, do not fail the line
+            extras["gpu_eager_baseline"] = {"error": repr(e)[:200]}
+
     if rank == 0:
         imgs = PER_GPU_BATCH * world * args.steps
         dom = max(fams, key=lambda k: fams[k][0])
@@ -219,34 +378,51 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         gemm_ms = sum(v[0] for v in fams.values())
         # L2 <-> fabric bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the committed
-        # summary of the two rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py) is quoted when present
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["families"][dom]["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        # summary of the two rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py) is quoted when it matches the sources
+        traffic, traffic_src = None, None
+        pmc = _quoted_profile("pmc_traffic")
+        if pmc is not None:
+            try:
+                traffic = pmc["families"][dom]["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{PROFILE_ROUND}_pmc_traffic.json (rocprofv3 PMC passes at {pmc.get('git_head', '?')}, kernel sources {pmc['kernel_sources_sha']})"
+            except Exception:
+                pass
+        mf = _quoted_profile("mfma_util")
+        swin = BACKBONE != "dinat"
         rec = {
-            "metric": "img/s fwd+bwd Swin-L 1024x2048 bs=2 per GPU" if BACKBONE != "dinat" else "img/s fwd+bwd DiNAT-L 1024x2048 bs=2 per GPU", "value": round(imgs / dt, 4), "unit": "img/s",
+            "metric": "img/s fwd+bwd Swin-L 1024x2048 bs=2 per GPU" if swin else "img/s fwd+bwd DiNAT-L 1024x2048 bs=2 per GPU",
+            "value": round(imgs / dt, 4), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: full OneFormer (Swin-L ws12 backbone + MSDeformAttn pixel decoder + "
-                                    "150-query masked-attention decoder), 1024x2048, fwd+bwd, synthetic loss") if BACKBONE != "dinat" else
+                                    "150-query masked-attention decoder), 1024x2048, fwd+bwd, synthetic loss") if swin else
                                    ("BASELINE configs[4]: full OneFormer with the DiNAT-L backbone (neighbourhood attention, kernel 7), "
-                                    "1024x2048, fwd+bwd, synthetic loss [UENC_BENCH_BACKBONE=dinat; model_tflop fields do not apply]"),
-                       "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
-                       "model_tflop_per_step_per_gpu": round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3, 2)},
-            "model_tflops_per_gpu": round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3 / (dt / args.steps), 1),
+                                    "1024x2048, fwd+bwd, synthetic loss [UENC_BENCH_BACKBONE=dinat]"),
+                       "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}", "mode": "eval() (train_mode reported separately)"},
+            "step_ms": {"median": round(statistics.median(step_ms), 3), "min": round(min(step_ms), 3), "max": round(max(step_ms), 3)},
+            "host_enqueue_ms": round(host_ms, 2),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, profiles/r01_pmc_traffic.json)",
+                         "frac": round(achieved / 2500.0, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(alg_bytes[dom] / max(n, 1)), "launches_per_step": n // max(args.steps, 1),
                          "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3),
                          "families": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,
-                                          "ms_per_step": round(v[0] / max(args.steps, 1), 2), "launches_per_step": v[2] // max(args.steps, 1)}
+                                          "ms_per_step": round(v[0] / max(args.steps, 1), 2), "launches_per_step": v[2] // max(args.steps, 1),
+                                          "algorithmic_bytes_per_step": round(alg_bytes[k] / max(args.steps, 1)),
+                                          "algorithmic_gbps": round(alg_bytes[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0}
                                       for k, v in fams.items()}},
-            "loss": round(float(loss.detach()), 5),
+            "loss": round(float(loss.detach()), 5) if "loss" in dir() else None,
         }
+        if swin:
+            rec["config"]["model_tflop_per_step_per_gpu"] = round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3, 2)
+            rec["model_tflops_per_gpu"] = round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3 / (dt / args.steps), 1)
+        if mf is not None:
+            rec["mfma_util"] = {k: mf[k] for k in ("mfma_busy_frac_of_step", "mfma_busy_frac_of_gpu_busy", "source") if k in mf}
+        rec.update(extras)
+        if dp_rec is not None:
+            rec["dp_check"] = dp_rec
+            with open(args.check_dp, "w") as f:
+                json.dump(dp_rec, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)

@@ -213,17 +213,21 @@ long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, i
  * q (B,Lq,*) / k, v (B,S,*) bf16 with heads interleaved in the row (head h at columns 32h..32h+31); *_bs / *_rs are
  * batch / row strides in elements (multiples of 8).  mask (B,Lq,mask_rs) bytes, shared by all heads, mask_rs a multiple
  * of 4 and >= S, or NULL.  out (B,Lq,*) bf16; lse (B,H,Lq) fp32 log2-domain log-sum-exp (needed by the backward).
- * workspace: uenc_mha_fwd_workspace_floats(...) floats (split-KV partials); NULL when that is 0. */
+ * workspace: uenc_mha_fwd_workspace_floats(...) floats (split-KV partials); NULL when that is 0.
+ * dropout_p in [0, 1), seed: dropout on the attention probabilities AFTER the softmax normalisation, as
+ * nn.MultiheadAttention(dropout=p) applies it in training mode (transformer.py:249-250, 0.1 in the class transformer): element
+ * (b, h, q, key) is kept iff hash(seed, ((b H + h) Lq + q) S + key) >= p 2^32 and scaled by 1 / (1 - p); the backward regenerates
+ * the mask from the same (p, seed).  0 = off (inference, and every masked-attention layer: their rate is 0.0, :326-344). */
 long uenc_mha_fwd_workspace_floats(int B, int H, int Lq, int S);
 int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
                  long v_rs, const unsigned char* mask, long mask_rs, void* out, long o_bs, long o_rs, float* lse,
-                 float* workspace, int B, int H, int Lq, int S, float scale, void* stream);
+                 float* workspace, int B, int H, int Lq, int S, float scale, float dropout_p, unsigned seed, void* stream);
 /* dq (B,Lq,*) fp32 ACCUMULATED (caller zeroes); dk, dv (B,S,*) bf16 overwritten for every key and head. */
 int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
                  long v_rs, const unsigned char* mask, long mask_rs, const void* out, long o_bs, long o_rs,
                  const float* lse, const void* dout, long do_bs, long do_rs, float* dq, long dq_bs, long dq_rs, void* dk,
                  long dk_bs, long dk_rs, void* dv, long dv_bs, long dv_rs, int B, int H, int Lq, int S, float scale,
-                 void* stream);
+                 float dropout_p, unsigned seed, void* stream);
 
 /* ---- neighbourhood attention 2-D (DiNAT backbone) -------------------------------------------------------------
  * What natten.NeighborhoodAttention2D computes between its qkv and proj Linear layers (reference call site
@@ -280,11 +284,11 @@ int uenc_window_attn_f32_bwd(const float* qkv, const float* qkv_bias, const floa
                              float* dbias_pad, int B, int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
 int uenc_mha_f32_fwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
                      const uint8_t* mask, long mask_row_stride, float* out, long os0, long os1, float* lse, int B, int nH, int Lq, int S,
-                     float scale, void* stream);
+                     float scale, float dropout_p, unsigned seed, void* stream);
 int uenc_mha_f32_bwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
                      const uint8_t* mask, long mask_row_stride, const float* out, long os0, long os1, const float* lse, const float* dout,
                      long gos0, long gos1, float* dq, long dqs0, long dqs1, float* dk, long dks0, long dks1, float* dv, long dvs0, long dvs1,
-                     float* delta, int B, int nH, int Lq, int S, float scale, void* stream);
+                     float* delta, int B, int nH, int Lq, int S, float scale, float dropout_p, unsigned seed, void* stream);
 
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */

@@ -95,3 +95,84 @@ def test_single_process_buckets_track_signals():
     m(torch.randn(4, 16)).sum().backward()
     assert all(gb._launched) or gb.world == 1
     gb.finish()
+
+
+def test_gradientless_parameters_are_excluded_and_grads_stay_in_the_flat_buffer():
+    """Parameters that receive no gradient on the path (the reference builds depth / pose / motion decoders unconditionally,
+    oneformer_model.py:143-145) leave the flat buffer after calibration; a .grad knocked out of the buffer is re-pointed by
+    zero_grad() and caught by finish()."""
+    sys.path.insert(0, os.path.join(ROOT, "uni-encoder-code_amd"))
+    from uenc.dp import GradBuckets
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.used = nn.Linear(8, 8)
+            self.unused = nn.Linear(8, 1024)
+
+        def forward(self, x):
+            return self.used(x)
+    m = M()
+    gb = GradBuckets(m, bucket_mb=0.004, listen_ops=False)
+    assert gb.flat.numel() == sum(p.numel() for p in m.parameters())
+    gb.zero_grad(); m(torch.randn(3, 8)).sum().backward(); gb.finish()
+    assert gb.flat.numel() == sum(p.numel() for p in m.used.parameters())          # excluded statically
+    assert m.unused.weight.grad is None and m.unused.bias.grad is None
+    want = m.used.weight.grad.clone()
+    # an optimizer-style zero_grad(set_to_none=True) detaches .grad from the buffer: zero_grad() repairs it ...
+    m.zero_grad(set_to_none=True)
+    gb.zero_grad()
+    assert m.used.weight.grad is not None and m.used.weight.grad.data_ptr() >= gb.flat.data_ptr()
+    torch.manual_seed(0); x = torch.randn(3, 8)
+    m(x).sum().backward(); gb.finish()
+    assert float(gb.flat.abs().sum()) > 0
+    # ... and finish() refuses to reduce a buffer the gradients did not go to
+    gb.zero_grad()
+    m.used.weight.grad = None
+    m(x).sum().backward()
+    with pytest.raises(RuntimeError):
+        gb.finish()
+    assert want.shape == m.used.weight.shape
+
+
+def _diverging_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "uni-encoder-code_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uenc.dp import GradBuckets
+    torch.manual_seed(rank)                                   # different initial weights per rank: must be overwritten by rank 0's
+    m = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 4))
+    gb = GradBuckets(m, listen_ops=False)
+    w0 = m[0].weight.detach().clone()
+    gb.zero_grad()
+    y = m[0](torch.ones(2, 4))
+    if rank == 0:
+        y = m[1](y)                                           # rank 1 skips a layer: a different graph
+    y.sum().backward()
+    try:
+        gb.finish()
+        q.put((rank, "no error", w0))
+    except RuntimeError as e:
+        q.put((rank, "raised" if "differ from rank 0" in str(e) else repr(e), w0))
+    dist.destroy_process_group()
+
+
+def test_replicas_are_broadcast_and_a_diverging_rank_is_caught():
+    world, port = 2, 29547
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_diverging_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, what, w0 = q.get(timeout=60)
+            got[r] = (what, w0)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert torch.equal(got[0][1], got[1][1])                  # parameters were broadcast from rank 0 at construction
+    assert got[0][0] == "no error" and got[1][0] == "raised"

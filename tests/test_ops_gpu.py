@@ -504,3 +504,120 @@ def test_patch_merge_ln_fn(ops, B, H, W, C):
     y2 = F.layer_norm(cat, (4 * C,), g2, b2, 1e-5)
     y2.backward(dy.to(torch.bfloat16).float())
     _check("y", y, y2, 5e-3); _check("dx", x.grad, x2.grad, 1e-4); _check("dg", g.grad, g2.grad, 1e-4); _check("db", b.grad, b2.grad, 1e-4)
+
+
+@pytest.mark.parametrize("exact_mode", [False, True])
+def test_mha_attention_probability_dropout(exact_mode):
+    """Dropout on the attention probabilities inside the attention kernels (nn.MultiheadAttention(dropout=0.1) in training mode,
+    reference transformer.py:249-250): forward and all three gradients against a dense fp64 attention that applies the same
+    keep-mask (rebuilt on the host from the seed), in the bf16 product kernels and in the fp32 exact-mode kernels."""
+    from uenc import ops
+    from uenc.attention import keep_mask_reference, mha
+    from conftest import record_parity
+    B, Lq, S, nH, E, p, seed = 2, 150, 200, 8, 256, 0.1, 12345
+    g = torch.Generator().manual_seed(3)
+    mk = lambda n: (torch.randn(B, n, E, generator=g) * 0.5)
+    q0, k0, v0 = mk(Lq), mk(S), mk(S)
+    mask = torch.rand(B, Lq, S, generator=g) < 0.3
+    mask[:, :, 0] = False
+    go = torch.randn(B, Lq, E, generator=g)
+    ops.set_exact(exact_mode)
+    try:
+        dt = torch.float32 if exact_mode else torch.bfloat16
+        q, k, v = (t.cuda().to(dt).requires_grad_() for t in (q0, k0, v0))
+        out = mha(q, k, v, nH, mask.cuda(), p, seed)
+        out.backward(go.cuda().to(dt))
+        out_nodrop = mha(q, k, v, nH, mask.cuda())
+    finally:
+        ops.set_exact(False)
+    keep = keep_mask_reference(B, nH, Lq, S, p, seed)
+    assert 0.88 < float(keep.float().mean()) < 0.92
+    qd, kd, vd = (t.detach().double().cpu().requires_grad_() for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, nH, 32).transpose(1, 2) for t in (qd, kd, vd))
+    s = (qh @ kh.transpose(-1, -2) / 32 ** 0.5).masked_fill(mask[:, None], float("-inf"))
+    ref = ((s.softmax(-1) * keep / (1.0 - float(torch.tensor(p)))) @ vh).transpose(1, 2).reshape(B, Lq, E)
+    ref.backward(go.to(dt).double())
+    rel = lambda a, b: float((a.detach().double().cpu() - b).norm() / b.norm())
+    figs = dict(out=rel(out, ref.detach()), dq=rel(q.grad, qd.grad), dk=rel(k.grad, kd.grad), dv=rel(v.grad, vd.grad))
+    record_parity(f"{'exact' if exact_mode else 'bf16'}/mha_dropout", **figs)
+    tol = 1e-5 if exact_mode else 2e-2
+    assert all(x < tol for x in figs.values()), figs
+    assert rel(out_nodrop, ref.detach()) > 0.1          # the mask really was applied
+
+
+def test_class_transformer_training_dropout_matches_explicit_masks():
+    """TransformerDecoderLayer in training mode (reference transformer.py:268-297 with dropout 0.1): our layer against the fp32 oracle
+    arithmetic with the SAME masks -- the elementwise keep-masks the layer recorded and the attention keep-masks rebuilt from its
+    seeds."""
+    from oracle import fill, torch_ref as T
+    from uenc.attention import keep_mask_reference
+    from uenc.modeling.transformer_decoder.oneformer_transformer_decoder import TransformerDecoderLayer
+    from conftest import record_parity
+    torch.manual_seed(0)
+    B, Q, S, E, nH = 2, 149, 96, 256, 8
+    layer = TransformerDecoderLayer(E, nH, 2048, 0.1).cuda()
+    fill.fill_module(layer, "sem_seg_head.predictor.class_transformer.decoder.layers.0.")
+    layer.train()
+    g = torch.Generator().manual_seed(5)
+    tgt, mem, key_in, qpos = (torch.randn(B, n, E, generator=g).cuda() for n in (Q, S, S, Q))
+    out = layer(tgt, mem, key_in, qpos)
+    m1, m2, m3, m4 = [m.cpu() for m in layer._masks]
+    keep_self = keep_mask_reference(B, nH, Q, Q, 0.1, layer.self_attn.last_seed)
+    keep_cross = keep_mask_reference(B, nH, Q, S, 0.1, layer.multihead_attn.last_seed)
+    sd = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    kp = 1.0 - float(torch.tensor(0.1))
+
+    def attn(qi, ki, vi, pre, keep):
+        W, b = sd[pre + ".in_proj_weight"], sd[pre + ".in_proj_bias"]
+        q = (qi @ W[:E].t() + b[:E]).view(B, -1, nH, 32).transpose(1, 2)
+        k = (ki @ W[E:2 * E].t() + b[E:2 * E]).view(B, -1, nH, 32).transpose(1, 2)
+        v = (vi @ W[2 * E:].t() + b[2 * E:]).view(B, -1, nH, 32).transpose(1, 2)
+        pr = (q @ k.transpose(-1, -2) / 32 ** 0.5).softmax(-1) * keep / kp
+        o = (pr @ v).transpose(1, 2).reshape(B, -1, E)
+        return o @ sd[pre + ".out_proj.weight"].t() + sd[pre + ".out_proj.bias"]
+    ln = lambda x, n: torch.nn.functional.layer_norm(x, (E,), sd[n + ".weight"], sd[n + ".bias"])
+    t, me, ki, qp = tgt.cpu(), mem.cpu(), key_in.cpu(), qpos.cpu()
+    t = ln(t + attn(t + qp, t + qp, t, "self_attn", keep_self) * m1 / kp, "norm1")
+    t = ln(t + attn(t + qp, ki, me, "multihead_attn", keep_cross) * m2 / kp, "norm2")
+    h = torch.relu(t @ sd["linear1.weight"].t() + sd["linear1.bias"]) * m3 / kp
+    t = ln(t + (h @ sd["linear2.weight"].t() + sd["linear2.bias"]) * m4 / kp, "norm3")
+    r = float((out.detach().float().cpu() - t).norm() / t.norm())
+    record_parity("bf16/class_transformer_layer_training_dropout", out=r)
+    assert r < 2e-2, r
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+    layer.eval()
+    o2 = layer(tgt, mem, key_in, qpos)
+    assert float((o2 - out).abs().max()) > 1e-3          # eval mode: no dropout
+
+
+def test_failed_backward_leaves_no_stale_wgrad_groups():
+    """A backward that raises skips the autograd engine's final callbacks: queued wgrad groups and held notifications must not leak
+    into the next pass (WgradQueue.reset at the start of a step)."""
+    from uenc import ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 256).cuda()
+    x = torch.randn(4096, 256, device="cuda")
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    def run(fail):
+        lin.zero_grad(set_to_none=True)
+        ops.CACHE.refresh()
+        h = Boom.apply(x.requires_grad_()) if fail else x
+        y = ops.linear(h, lin.weight, lin.bias, out_dtype=torch.float32)
+        y.square().mean().backward()          # the queued wgrad group is flushed by the end-of-backward callback
+        return lin.weight.grad.clone()
+    clean = run(False)
+    with pytest.raises(RuntimeError):
+        run(True)
+    assert ops.WGRADS.callback_armed            # what the failed pass leaves behind ...
+    again = run(False)                          # ... is dropped at the start of the next step (ParamCache.refresh -> WGRADS.reset)
+    torch.testing.assert_close(again, clean, rtol=1e-5, atol=1e-7)

@@ -101,4 +101,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Dropout on attention probabilities (nn.MultiheadAttention(dropout=p) in training mode, reference
+// transformer_decoder/transformer.py:249-250): element (b, h, q, key) is KEPT iff hash(seed, index) >= p * 2^32.  A pure function of
+// the index, so forward, dQ and dK / dV kernels (and the fp32 exact-mode kernels) regenerate the same mask without storing it.
+__device__ __forceinline__ bool attn_keep(unsigned seed, unsigned thresh, unsigned long long idx) {
+    unsigned x = ((unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B9u)) + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x >= thresh;
+}
+static inline unsigned attn_drop_thresh(float p) { return p <= 0.f ? 0u : (p >= 1.f ? 0xffffffffu : (unsigned)((double)p * 4294967296.0)); }
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -384,6 +384,8 @@ struct XMha {
     long gos0, gos1, dqs0, dqs1, dks0, dks1, dvs0, dvs1;
     int B, nH, Lq, S;
     float scale;
+    unsigned drop_thresh, seed;
+    float inv_keep;
 };
 
 constexpr int XQW = 2, XQB = 8;
@@ -426,8 +428,11 @@ __global__ __launch_bounds__(256) void xmha_fwd_kernel(XMha p) {
             for (int d = 0; d < XHD; ++d) s = fmaf(qv[i][d], kr[d], s);
             const float mn = fmaxf(m[i], s), c = expf(m[i] - mn), e = expf(s - mn);
             l[i] = l[i] * c + e;
+            float ed = e;                                   // dropout after the normaliser
+            if (p.drop_thresh != 0u)
+                ed = attn_keep(p.seed, p.drop_thresh, (((unsigned long long)b * p.nH + h) * p.Lq + qi) * p.S + key) ? e * p.inv_keep : 0.f;
 #pragma unroll
-            for (int d = 0; d < XHD; ++d) acc[i][d] = fmaf(e, vr[d], acc[i][d] * c);
+            for (int d = 0; d < XHD; ++d) acc[i][d] = fmaf(ed, vr[d], acc[i][d] * c);
             m[i] = mn;
         }
     }
@@ -491,12 +496,15 @@ __global__ __launch_bounds__(256) void xmha_bwd_kernel(XMha p) {
 #pragma unroll
             for (int d = 0; d < XHD; ++d) { s = fmaf(qv[i][d], kr[d], s); dp = fmaf(go[i][d], vr[d], dp); }
             const float pr = expf(s - lse[i]);
-            const float ds = pr * (dp - dl[i]);
+            float keepw = 1.0f;
+            if (p.drop_thresh != 0u)
+                keepw = attn_keep(p.seed, p.drop_thresh, (((unsigned long long)b * p.nH + h) * p.Lq + qi) * p.S + key) ? p.inv_keep : 0.f;
+            const float ds = pr * (dp * keepw - dl[i]);
 #pragma unroll
             for (int d = 0; d < XHD; ++d) {
                 dq[i][d] = fmaf(ds, kr[d], dq[i][d]);
                 dkr[d] = fmaf(ds, qv[i][d], dkr[d]);
-                dvr[d] = fmaf(pr, go[i][d], dvr[d]);
+                dvr[d] = fmaf(pr * keepw, go[i][d], dvr[d]);
             }
             any = true;
         }
@@ -534,13 +542,15 @@ __global__ void xmha_delta_kernel(const float* out, long os0, long os1, const fl
 
 extern "C" int uenc_mha_f32_fwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
                                 const uint8_t* mask, long mask_row_stride, float* out, long os0, long os1, float* lse, int B, int nH, int Lq,
-                                int S, float scale, hipStream_t stream) {
+                                int S, float scale, float dropout_p, unsigned seed, hipStream_t stream) {
     UENC_CHECK_ARG(q != nullptr && k != nullptr && v != nullptr && out != nullptr && B > 0 && nH > 0 && Lq > 0 && S > 0);
+    UENC_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
     if (mask != nullptr) UENC_CHECK_ARG(mask_row_stride >= S);
     XMha p{};
     p.q = q; p.k = k; p.v = v; p.mask = mask; p.out = out; p.lse = lse;
     p.qs0 = qs0; p.qs1 = qs1; p.ks0 = ks0; p.ks1 = ks1; p.vs0 = vs0; p.vs1 = vs1; p.os0 = os0; p.os1 = os1; p.mrs = mask_row_stride;
     p.B = B; p.nH = nH; p.Lq = Lq; p.S = S; p.scale = scale;
+    p.drop_thresh = attn_drop_thresh(dropout_p); p.seed = seed; p.inv_keep = 1.0f / (1.0f - dropout_p);
     hipLaunchKernelGGL(xmha_fwd_kernel, dim3((Lq + XQB - 1) / XQB, nH, B), dim3(256), 0, stream, p);
     UENC_LAUNCH_RET();
 }
@@ -549,7 +559,9 @@ extern "C" int uenc_mha_f32_fwd(const float* q, long qs0, long qs1, const float*
 extern "C" int uenc_mha_f32_bwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
                                 const uint8_t* mask, long mask_row_stride, const float* out, long os0, long os1, const float* lse,
                                 const float* dout, long gos0, long gos1, float* dq, long dqs0, long dqs1, float* dk, long dks0, long dks1,
-                                float* dv, long dvs0, long dvs1, float* delta, int B, int nH, int Lq, int S, float scale, hipStream_t stream) {
+                                float* dv, long dvs0, long dvs1, float* delta, int B, int nH, int Lq, int S, float scale, float dropout_p,
+                                unsigned seed, hipStream_t stream) {
+    UENC_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
     UENC_CHECK_ARG(q != nullptr && k != nullptr && v != nullptr && out != nullptr && lse != nullptr && dout != nullptr);
     UENC_CHECK_ARG(dq != nullptr && dk != nullptr && dv != nullptr && delta != nullptr && B > 0 && nH > 0 && Lq > 0 && S > 0);
     if (mask != nullptr) UENC_CHECK_ARG(mask_row_stride >= S);
@@ -560,6 +572,7 @@ extern "C" int uenc_mha_f32_bwd(const float* q, long qs0, long qs1, const float*
     p.qs0 = qs0; p.qs1 = qs1; p.ks0 = ks0; p.ks1 = ks1; p.vs0 = vs0; p.vs1 = vs1; p.mrs = mask_row_stride;
     p.gos0 = gos0; p.gos1 = gos1; p.dqs0 = dqs0; p.dqs1 = dqs1; p.dks0 = dks0; p.dks1 = dks1; p.dvs0 = dvs0; p.dvs1 = dvs1;
     p.B = B; p.nH = nH; p.Lq = Lq; p.S = S; p.scale = scale;
+    p.drop_thresh = attn_drop_thresh(dropout_p); p.seed = seed; p.inv_keep = 1.0f / (1.0f - dropout_p);
     hipLaunchKernelGGL(xmha_bwd_kernel, dim3((Lq + XQB - 1) / XQB, nH, B), dim3(256), 0, stream, p);
     UENC_LAUNCH_RET();
 }

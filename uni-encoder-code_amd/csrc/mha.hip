@@ -40,6 +40,8 @@ struct MhaP {
     bf16 *dk, *dv; long dk_bs, dk_rs, dv_bs, dv_rs;
     int B, H, Lq, S, nsplit, keys_per_split;
     float scale;
+    unsigned drop_thresh, seed;                     // attention-probability dropout (0 = off): attn_keep() of common.h
+    float inv_keep;
 };
 
 __device__ __forceinline__ void stage_rows(unsigned char* img, const bf16* base, long rs, int row0, int nrows, int nvalid,
@@ -167,8 +169,11 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float e = ok[kt][r] ? fast_exp2(s[kt][r] - mnew) : 0.f;
+                        sum += e;                                    // the softmax normaliser is taken BEFORE dropout
                         s[kt][r] = e;
-                        sum += e;
+                        if (p.drop_thresh != 0u)
+                            s[kt][r] = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
+                                           ? e * p.inv_keep : 0.f;
                     }
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
@@ -195,7 +200,11 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pr = ok[kt][r] ? fast_exp2(s[kt][r] - lse_q[i]) : 0.f;
-                        s[kt][r] = pr * (dp[r] - dl_q[i]);
+                        float dpv = dp[r];
+                        if (p.drop_thresh != 0u)
+                            dpv = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
+                                      ? dpv * p.inv_keep : 0.f;
+                        s[kt][r] = pr * (dpv - dl_q[i]);
                     }
                 }
 #pragma unroll
@@ -356,8 +365,11 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
                     bool ok = (key < k_end) && (qi < p.Lq);
                     if (ok && p.mask != nullptr) ok = p.mask[((long)b * p.Lq + qi) * p.mask_rs + key] == 0;
                     const float pr = ok ? fast_exp2(sv[r] * sc - lv[r]) : 0.f;
-                    pt[h2][r] = pr;
-                    dst[h2][r] = pr * (dp[r] - dv4[r]);
+                    float keepw = 1.0f;
+                    if (p.drop_thresh != 0u && ok)
+                        keepw = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qi) * p.S + key) ? p.inv_keep : 0.f;
+                    pt[h2][r] = pr * keepw;
+                    dst[h2][r] = pr * (dp[r] * keepw - dv4[r]);
                 }
             }
             bf16x8 pb, db;
@@ -411,7 +423,10 @@ extern "C" long uenc_mha_fwd_workspace_floats(int B, int H, int Lq, int S) {
 }
 
 static int mha_fill(MhaP& p, const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
-                    long v_rs, const unsigned char* mask, long mask_rs, int B, int H, int Lq, int S, float scale) {
+                    long v_rs, const unsigned char* mask, long mask_rs, int B, int H, int Lq, int S, float scale, float dropout_p,
+                    unsigned seed) {
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return UENC_EINVAL;
+    p.drop_thresh = attn_drop_thresh(dropout_p); p.seed = seed; p.inv_keep = 1.0f / (1.0f - dropout_p);
     if (!(q && k && v && B > 0 && H > 0 && Lq > 0 && S > 0)) return UENC_EINVAL;
     if ((q_rs | k_rs | v_rs | q_bs | k_bs | v_bs) & 7) return UENC_EINVAL;                   // 16-byte rows
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return UENC_EINVAL;
@@ -424,13 +439,14 @@ static int mha_fill(MhaP& p, const void* q, long q_bs, long q_rs, const void* k,
     return UENC_OK;
 }
 
+// dropout_p / seed: dropout on the attention probabilities (training mode of nn.MultiheadAttention(dropout=p)); 0 = off.
 // out (B, Lq, H*32-wide rows) bf16; lse (B, H, Lq) fp32 (log2 domain, needed by the backward; may be NULL);
 // workspace: uenc_mha_fwd_workspace_floats() floats (may be NULL when that is 0).
 extern "C" int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
                             long v_rs, const unsigned char* mask, long mask_rs, void* out, long o_bs, long o_rs, float* lse, float* workspace,
-                            int B, int H, int Lq, int S, float scale, hipStream_t stream) {
+                            int B, int H, int Lq, int S, float scale, float dropout_p, unsigned seed, hipStream_t stream) {
     MhaP p;
-    int rc = mha_fill(p, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, mask, mask_rs, B, H, Lq, S, scale);
+    int rc = mha_fill(p, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, mask, mask_rs, B, H, Lq, S, scale, dropout_p, seed);
     if (rc != UENC_OK) return rc;
     UENC_CHECK_ARG(out && (o_rs % 4 == 0) && (o_bs % 4 == 0));
     p.out = (bf16*)out; p.o_bs = o_bs; p.o_rs = o_rs; p.lse = lse;
@@ -452,10 +468,10 @@ extern "C" int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, 
 extern "C" int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
                             long v_rs, const unsigned char* mask, long mask_rs, const void* out, long o_bs, long o_rs, const float* lse,
                             const void* dout, long do_bs, long do_rs, float* dq, long dq_bs, long dq_rs, void* dk, long dk_bs,
-                            long dk_rs, void* dv, long dv_bs, long dv_rs, int B, int H, int Lq, int S, float scale,
-                            hipStream_t stream) {
+                            long dk_rs, void* dv, long dv_bs, long dv_rs, int B, int H, int Lq, int S, float scale, float dropout_p,
+                            unsigned seed, hipStream_t stream) {
     MhaP p;
-    int rc = mha_fill(p, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, mask, mask_rs, B, H, Lq, S, scale);
+    int rc = mha_fill(p, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, mask, mask_rs, B, H, Lq, S, scale, dropout_p, seed);
     if (rc != UENC_OK) return rc;
     UENC_CHECK_ARG(out && lse && dout && dq && dk && dv);
     UENC_CHECK_ARG(((o_rs | do_rs | o_bs | do_bs) & 7) == 0 && ((dk_rs | dv_rs | dk_bs | dv_bs) & 3) == 0);

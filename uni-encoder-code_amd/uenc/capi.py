@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libuenc_hip.so")
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_MUL_DGELU, EPI_MUL_DRELU = range(6)
 
-c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+c_p, c_i, c_l, c_f, c_u = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint
 
 # name -> argtypes; every function returns int unless noted
 _SIGNATURES = {
@@ -51,9 +51,9 @@ _SIGNATURES = {
     "uenc_msdeform_attn_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p],
     "uenc_msdeform_attn_bwd_workspace_bytes": [c_p, c_i, c_i, c_i, c_i, c_i, c_i],
     "uenc_mha_fwd_workspace_floats": [c_i, c_i, c_i, c_i],
-    "uenc_mha_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_mha_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_mha_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
-                     c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_p],
+                     c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_window_attn_np": [c_i],
     "uenc_relpos_expand": [c_p, c_p, c_p, c_i, c_i, c_p],
     "uenc_window_attn_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
@@ -72,9 +72,9 @@ _SIGNATURES = {
     "uenc_gemm_tn_f32": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "uenc_window_attn_f32_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_window_attn_f32_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
-    "uenc_mha_f32_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_mha_f32_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_mha_f32_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
-                         c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+                         c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 }
 

@@ -15,7 +15,12 @@ Design for MI355X / xGMI:
   * buckets are laid out in the order gradients became final during calibration (true backward
     order), and a bucket's all-reduce is launched asynchronously (RCCL's stream) the moment its last
     gradient is final, overlapping the rest of backward;
-  * parameters that never receive a gradient on this path are left out.
+  * parameters that never receive a gradient on this path (the depth / pose / motion decoders the reference builds
+    unconditionally, oneformer_model.py:143-145) are dropped from the flat buffer after the calibration step: they are
+    neither stored nor reduced;
+  * replicas are made identical at construction (parameters and buffers broadcast from rank 0, as DDP does), and the bucket
+    layout every rank uses is rank 0's: the observed order and contribution counts are broadcast after calibration and each
+    rank checks that its own observation agrees, so ranks can never reduce different parameters against each other.
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
 """
 from typing import Dict, List, Optional
@@ -31,6 +36,11 @@ class GradBuckets:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.cap = max(1, int(bucket_mb * (1 << 20) / 4))
         self.params: List[nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        if self.world > 1:                      # identical replicas, whatever each rank's initialisation did
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
         self._index: Dict[int, int] = {id(p): i for i, p in enumerate(self.params)}
         self._expected: Optional[List[int]] = None          # contributions per parameter per step
         self._count = [0] * len(self.params)
@@ -49,12 +59,14 @@ class GradBuckets:
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.bucket_ranges, self._bucket_of, self._bucket_pending0 = [], {}, []
+        self._views: Dict[int, torch.Tensor] = {}
         off = start = 0
         members = 0
         for i in order:
             p = self.params[i]
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._views[i] = self.flat[off:off + n].view_as(p)
+            p.grad = self._views[i]
             self._bucket_of[i] = len(self.bucket_ranges)
             off += n
             members += 1
@@ -96,7 +108,18 @@ class GradBuckets:
 
     # ---- step protocol --------------------------------------------------------------------------
     def zero_grad(self):
+        """Start of a step: zero the flat buffer and re-point every .grad at its slice of it (a `zero_grad(set_to_none=True)`
+        or an optimizer that replaced .grad would otherwise leave the kernels accumulating outside the reduced buffer)."""
         self.flat.zero_()
+        for i, v in self._views.items():
+            p = self.params[i]
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+        try:
+            from . import ops
+            ops.WGRADS.reset()                  # a backward that raised leaves queued groups / held notifications behind
+        except Exception:
+            pass
         self._count = [0] * len(self.params)
         self._pending = list(self._bucket_pending0)
         self._launched = [False] * len(self.bucket_ranges)
@@ -115,19 +138,34 @@ class GradBuckets:
         self._works = []
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
+        for i, v in self._views.items():         # the reduced buffer must be what the kernels accumulated into
+            g = self.params[i].grad
+            if g is None or g.data_ptr() != v.data_ptr():
+                raise RuntimeError("GradBuckets: a parameter's .grad no longer aliases the flat all-reduce buffer "
+                                   "(call GradBuckets.zero_grad(), not optimizer.zero_grad(set_to_none=True))")
         if self._calibrating:
             self._calibrating = False
-            self._expected = list(self._count)
-            silent = [i for i in range(len(self.params)) if self._count[i] == 0]
-            order = self._order + silent       # parameters that got no gradient go last and never gate a launch
-            old = {i: self.params[i].grad.clone() for i in range(len(self.params))}
-            self._layout(order)
+            expected, order = list(self._count), list(self._order)
+            if self.world > 1:
+                # one layout for every rank: rank 0's observation is broadcast; a rank whose own backward produced a different
+                # set of gradients has a different graph and must not silently reduce against the others
+                box = [(expected, order)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                           group=self.group)
+                if box[0][0] != expected:
+                    bad = [i for i, (a, b) in enumerate(zip(box[0][0], expected)) if a != b]
+                    raise RuntimeError(f"GradBuckets: gradient contributions differ from rank 0 for parameters {bad[:8]} "
+                                       "(replicas must run the same graph)")
+                expected, order = box[0]
+            self._expected = expected
+            active = [i for i in order if expected[i] > 0]
+            old = {i: self.params[i].grad.clone() for i in active}
+            for i in range(len(self.params)):       # gradient-less parameters: excluded statically, neither stored nor reduced
+                if expected[i] == 0:
+                    self.params[i].grad = None
+            self._layout(active)
             for i, gi in old.items():
                 self.params[i].grad.copy_(gi)
-            # silent parameters must not keep a bucket waiting
-            for i in silent:
-                self._bucket_pending0[self._bucket_of[i]] -= 1
-            self._pending = list(self._bucket_pending0)
 
     def close(self):
         for h in self._hooks:

@@ -186,6 +186,10 @@ class SwinTransformer(nn.Module):
         super().__init__()
         if ape:
             raise NotImplementedError("absolute position embedding is not on the shipped config's path (APE: False)")
+        if drop_rate != 0.0 or attn_drop_rate != 0.0:
+            # refused rather than silently ignored: a model built with these would train differently from the reference's
+            raise NotImplementedError("MODEL.SWIN.DROP_RATE / ATTN_DROP_RATE > 0 are not implemented in the fused Swin block "
+                                      "(0.0 in every shipped config, config.py:192-214); stochastic depth (DROP_PATH_RATE) is")
         self.pretrain_img_size, self.num_layers, self.embed_dim = pretrain_img_size, len(depths), embed_dim
         self.ape, self.patch_norm, self.out_indices, self.frozen_stages = ape, patch_norm, out_indices, frozen_stages
         self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, norm_layer if patch_norm else None)

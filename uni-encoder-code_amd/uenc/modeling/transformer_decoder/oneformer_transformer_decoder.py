@@ -12,7 +12,10 @@ Differences in how it runs: batch-first `(B, L, E)` tokens instead of `(L, B, E)
 FFN is a bf16 MFMA GEMM with fused bias / ReLU / residual epilogues; post-norm `LN(x + f(x))` is one
 LayerNorm kernel reading the GEMM's residual-fused output; the mask einsum is a batched NT GEMM over
 channels-last mask features; attention cores go through `ops.attention` (HIP flash-style kernels).
-Eval-mode semantics (dropout = identity), post-norm only (`PRE_NORM: False` in every shipped config).
+Training mode: the class transformer's dropout (`ONE_FORMER.DROPOUT`, 0.1) is applied as in the reference -- on the attention
+probabilities inside the HIP attention kernels (hash-derived keep-mask) and as dropout1 / 2 / 3 + the FFN's inner dropout
+(transformer.py:249-260, 283-296); the nine masked-attention layers have rate 0.0 hard-coded in the reference (:326-344).
+Post-norm only (`PRE_NORM: False` in every shipped config).
 """
 import logging
 from typing import Optional
@@ -45,6 +48,8 @@ class MultiheadAttention(nn.Module):
     def __init__(self, embed_dim, num_heads, dropout=0.0):
         super().__init__()
         self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.dropout = float(dropout)           # on the attention probabilities, training mode only (nn.MultiheadAttention semantics)
+        self.last_seed = None                   # seed of the last training forward (tests rebuild the keep-mask from it)
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
         self.out_proj = nn.Linear(embed_dim, embed_dim)
@@ -60,7 +65,11 @@ class MultiheadAttention(nn.Module):
             q = ops.linear(query, W, b, rows=(0, E))
             k = ops.linear(key, W, b, rows=(E, 2 * E))
         v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
-        o = ops.attention(q, k, v, self.num_heads, attn_mask)
+        if self.training and self.dropout > 0.0:
+            self.last_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)))      # torch's CPU generator: no device sync
+            o = ops.attention(q, k, v, self.num_heads, attn_mask, self.dropout, self.last_seed)
+        else:
+            o = ops.attention(q, k, v, self.num_heads, attn_mask)
         if residual is not None:
             return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, out_dtype=torch.float32)
@@ -135,8 +144,27 @@ class TransformerDecoderLayer(nn.Module):
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout_p = float(dropout)         # dropout, dropout1 / 2 / 3 of the reference (transformer.py:251, 258-260), training only
+        self._masks = []                        # keep-masks of the last training forward, in order (tests)
+
+    def _drop(self, t):
+        """Inverted dropout with an explicit keep-mask (torch.nn.Dropout semantics: x * mask / keep_prob)."""
+        keep = 1.0 - self.dropout_p
+        mask = torch.rand(t.shape, device=t.device) < keep
+        self._masks.append(mask)
+        return t * (mask.to(t.dtype) / keep)
 
     def forward(self, tgt, memory, key_in, query_pos):
+        if self.training and self.dropout_p > 0.0:
+            # training: the residual / FFN fusions are split where the reference applies dropout1 / 2 / 3 and the FFN's inner dropout
+            # (transformer.py:283-296); the attention-probability dropout runs inside the attention kernels
+            self._masks = []
+            qk = tgt + query_pos
+            tgt = _ln(self.norm1, tgt + self._drop(self.self_attn(qk, qk, tgt)))
+            tgt = _ln(self.norm2, tgt + self._drop(self.multihead_attn(tgt + query_pos, key_in, memory)))
+            h = self._drop(F.relu(ops.linear(tgt, self.linear1.weight, self.linear1.bias, out_dtype=torch.float32)))
+            h = ops.linear(h, self.linear2.weight, self.linear2.bias, out_dtype=torch.float32)
+            return _ln(self.norm3, tgt + self._drop(h))
         qk = tgt + query_pos
         tgt = _ln(self.norm1, self.self_attn(qk, qk, tgt, residual=tgt))
         tgt = _ln(self.norm2, self.multihead_attn(tgt + query_pos, key_in, memory, residual=tgt))

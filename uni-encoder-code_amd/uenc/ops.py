@@ -113,6 +113,7 @@ class ParamCache:
         """Re-cast every cached operand copy from its (updated) fp32 master, in one launch."""
         import numpy as np
         from .capi import check, lib, stream_ptr
+        WGRADS.reset()                              # start of a step: nothing of an earlier (failed) backward may survive
         if not self._store:
             return
         dead = [k for k, e in self._store.items() if e[3]() is None or e[4] is None or e[3]().data_ptr() != e[1]]
@@ -302,6 +303,14 @@ class WgradQueue:
     def _end_of_backward(self):
         self.callback_armed = False
         self.flush()
+
+    def reset(self):
+        """Drop whatever a previous, FAILED backward left queued (the engine skips its final callbacks when a node raises, so
+        `callback_armed` would stay set and the stale groups would be launched -- a step late -- with the next pass)."""
+        self.pending = {256: [], 128: []}
+        self.items = {256: 0, 128: 0}
+        self.small, self.small_items, self.notify = [], 0, []
+        self.callback_armed = False
 
     def flush(self):
         """Launch everything queued (both tile classes), then release the held gradient-ready notifications."""
@@ -933,10 +942,11 @@ def mask_heads(mf32_tok, mf16_chw, pre, mes):
 # --------------------------------------------------------------------------------------------
 # multi-head attention core of the decoder (head_dim 32): q (B, Lq, E), k / v (B, S, E)
 # --------------------------------------------------------------------------------------------
-def attention(q, k, v, nheads: int, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """softmax(q k^T / sqrt(d) [blocked where mask]) v, heads interleaved in E.  -> (B, Lq, E) bf16."""
+def attention(q, k, v, nheads: int, mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d) [blocked where mask]) v, heads interleaved in E.  -> (B, Lq, E) bf16.
+    dropout_p > 0: dropout on the attention probabilities (training), keep-mask derived from `seed` inside the kernels."""
     from .attention import mha
-    return mha(q, k, v, nheads, mask)
+    return mha(q, k, v, nheads, mask, dropout_p, seed)
 
 
 # --------------------------------------------------------------------------------------------
