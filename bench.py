@@ -298,6 +298,7 @@ def main():
         evs[i][1].record()
     sync()
     dt = time.perf_counter() - t0
+    loss_val = float(loss.detach())
     step_ms = [a.elapsed_time(b) for a, b in evs]
     # host cost of one step, enqueued into an idle stream (the GPU is behind the host for the whole call)
     t1 = time.perf_counter()
@@ -362,7 +363,7 @@ def main():
                                 "what": "model.train(): DropPath (dropped residual branches of a sample are skipped, kept ones scaled), "
                                         "dropout 0.1 in the deformable encoder layers and the class transformer"}
         try:
-            del loss
+            loss = None
             buckets.zero_grad()
             torch.cuda.empty_cache()
             eb = gpu_eager_baseline(device)
@@ -411,7 +412,7 @@ def main():
                                           "algorithmic_bytes_per_step": round(alg_bytes[k] / max(args.steps, 1)),
                                           "algorithmic_gbps": round(alg_bytes[k] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0}
                                       for k, v in fams.items()}},
-            "loss": round(float(loss.detach()), 5) if "loss" in dir() else None,
+            "loss": round(loss_val, 5),
         }
         if swin:
             rec["config"]["model_tflop_per_step_per_gpu"] = round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3, 2)

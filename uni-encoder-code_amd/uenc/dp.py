@@ -37,10 +37,16 @@ class GradBuckets:
         self.cap = max(1, int(bucket_mb * (1 << 20) / 4))
         self.params: List[nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         if self.world > 1:                      # identical replicas, whatever each rank's initialisation did
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            staged = dist.get_backend(process_group) == "gloo"
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
-                    dist.broadcast(t.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
-                                   group=process_group)
+                    if staged and t.is_cuda:            # gloo rehearsal on a GPU: through host memory
+                        host = t.data.cpu()
+                        dist.broadcast(host, src=src, group=process_group)
+                        t.data.copy_(host)
+                    else:
+                        dist.broadcast(t.data, src=src, group=process_group)
         self._index: Dict[int, int] = {id(p): i for i, p in enumerate(self.params)}
         self._expected: Optional[List[int]] = None          # contributions per parameter per step
         self._count = [0] * len(self.params)
@@ -104,6 +110,13 @@ class GradBuckets:
         self._launched[b] = True
         if self.world > 1:
             s, e = self.bucket_ranges[b]
+            if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                # functional rehearsal of N ranks on fewer GPUs (bench.py, UENC_DIST_BACKEND=gloo): the bucket is staged through
+                # host memory, synchronously -- correctness of the signalling / bucketing, not a performance path
+                host = self.flat[s:e].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat[s:e].copy_(host)
+                return
             self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ---- step protocol --------------------------------------------------------------------------
