@@ -1,0 +1,171 @@
+"""Checkpoint ingest: wrapper pickles / .pth, the three conversion tools, suffix matching, the legacy-key
+shims, and the refusal to execute anything a checkpoint file contains.  CPU only (name-hashed weights: no checkpoint ships)."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS = os.path.join(ROOT, "uni-encoder-code_amd", "tools")
+
+
+def _small_model():
+    import model  # noqa: F401
+    from oracle import fill
+    from uenc.config import add_common_config, add_swin_config, add_uni_encoder_config
+    from uenc.d2 import build_model, get_cfg
+    cfg = get_cfg()
+    add_common_config(cfg); add_swin_config(cfg); add_uni_encoder_config(cfg)
+    cfg.merge_from_list([
+        "MODEL.META_ARCHITECTURE", "OneFormer", "MODEL.BACKBONE.NAME", "D2SwinTransformer", "MODEL.SWIN.EMBED_DIM", 64,
+        "MODEL.SWIN.DEPTHS", [2, 2, 2, 2], "MODEL.SWIN.NUM_HEADS", [2, 4, 8, 16], "MODEL.SEM_SEG_HEAD.NAME", "OneFormerHead",
+        "MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME", "MSDeformAttnPixelDecoder", "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 19,
+        "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.IN_FEATURES", ["res2", "res3", "res4", "res5"],
+        "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", 6,
+        "MODEL.ONE_FORMER.TRANSFORMER_IN_FEATURE", "multi_scale_pixel_decoder", "MODEL.ONE_FORMER.NUM_OBJECT_QUERIES", 150,
+        "MODEL.ONE_FORMER.DEC_LAYERS", 10, "MODEL.IS_TRAIN", False, "MODEL.DEVICE", "cpu"])
+    m = build_model(cfg)
+    return m, fill
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_wrapper_round_trip_and_oracle_state_dict(tmp_path):
+    """product state_dict -> wrapper .pkl -> fresh model: identical tensors; the same file is a valid state dict for the oracle."""
+    from oracle import torch_ref as T
+    from uenc.checkpoint import DetectionCheckpointer, read_checkpoint, write_wrapper
+    m, fill = _small_model()
+    fill.fill_module(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    path = str(tmp_path / "model_final.pkl")
+    write_wrapper(path, sd)
+    with open(path, "rb") as f:                          # the on-disk format is the reference's wrapper
+        raw = pickle.load(f)
+    assert set(raw) == {"model", "__author__", "matching_heuristics"} and raw["__author__"] == "third_party"
+    assert all(isinstance(v, np.ndarray) for v in raw["model"].values())
+    m2, _ = _small_model()
+    rep = DetectionCheckpointer(m2).load(path)
+    assert rep["missing_keys"] == [] and rep["unexpected_keys"] == [] and rep["incorrect_shapes"] == []
+    _same(dict(m2.state_dict()), sd)
+    # the oracle consumes the same file as its state dict (names + shapes are the reference's)
+    osd = read_checkpoint(path)["model"]
+    want = T.model_param_shapes(T.ModelCfg(swin=T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7)))
+    assert {k: tuple(v.shape) for k, v in osd.items() if "relative_position_index" not in k} == {k: tuple(s) for k, s in want.items()}
+    img = torch.randint(0, 256, (3, 32, 64), generator=torch.Generator().manual_seed(0)).float()
+    with torch.no_grad():
+        out = T.oneformer_forward([{"left_image": img, "task": "The task is semantic"}], {k: v.float() for k, v in osd.items()},
+                                  T.ModelCfg(swin=T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7)), upsample=False)
+    assert torch.isfinite(out["pred_logits"]).all()
+
+
+def test_pth_and_reference_style_tensor_pickle(tmp_path):
+    """.pth (torch.save) and a wrapper written the way the reference's tools write it (plain pickle of torch tensors) both load."""
+    from uenc.checkpoint import DetectionCheckpointer, read_checkpoint
+    m, fill = _small_model()
+    fill.fill_module(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ck = DetectionCheckpointer(m, save_dir=str(tmp_path))
+    fn = ck.save("model_0000001", iteration=1)
+    assert open(tmp_path / "last_checkpoint").read() == "model_0000001.pth"
+    _same(read_checkpoint(fn)["model"], sd)
+    ref_style = str(tmp_path / "ref_style.pkl")
+    with open(ref_style, "wb") as f:                     # tools/convert-pretrained-model-to-d2.py:26-30 does exactly this
+        pickle.dump({"model": sd, "__author__": "third_party", "matching_heuristics": False}, f)
+    got = read_checkpoint(ref_style)
+    _same(got["model"], sd)
+    m2, _ = _small_model()
+    rep = DetectionCheckpointer(m2, save_dir=str(tmp_path)).resume_or_load("", resume=True)      # follows last_checkpoint
+    assert rep["missing_keys"] == []
+    _same(dict(m2.state_dict()), sd)
+
+
+def test_tools_convert_merge_and_suffix_matching(tmp_path):
+    """A raw backbone release (keys without the `backbone.` prefix) -> convert tool -> merge tool with a second partial checkpoint
+    -> load with matching_heuristics: the backbone keys land on `backbone.*`, the other file's keys override on a clash."""
+    from uenc.checkpoint import DetectionCheckpointer, read_checkpoint
+    m, fill = _small_model()
+    fill.fill_module(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    raw_backbone = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    torch.save({"model": raw_backbone}, tmp_path / "swin_release.pth")
+    head = {k: v + 1.0 for k, v in sd.items() if k.startswith("sem_seg_head.pixel_decoder.input_proj")}
+    head["patch_embed.proj.bias"] = raw_backbone["patch_embed.proj.bias"] + 2.0       # clashes with the first file: second wins
+    torch.save(head, tmp_path / "other.pth")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "uni-encoder-code_amd"))
+    run = lambda *a: subprocess.run([sys.executable, *a], check=True, env=env, cwd=str(tmp_path))
+    run(os.path.join(TOOLS, "convert-pretrained-model-to-d2.py"), "swin_release.pth", "swin.pkl")
+    run(os.path.join(TOOLS, "convert-pretrained-nat-model-to-d2.py"), "other.pth", "other.pkl")
+    run(os.path.join(TOOLS, "merge_two_pretrained_models.py"), "swin.pkl", "other.pkl", "merged.pkl")
+    a, b, c = (read_checkpoint(str(tmp_path / n)) for n in ("swin.pkl", "other.pkl", "merged.pkl"))
+    assert a["matching_heuristics"] is False and b["matching_heuristics"] is True and c["matching_heuristics"] is True
+    assert set(c["model"]) == set(raw_backbone) | set(head)
+    m2, _ = _small_model()
+    before = {k: v.clone() for k, v in m2.state_dict().items()}
+    rep = DetectionCheckpointer(m2).load(str(tmp_path / "merged.pkl"))
+    after = m2.state_dict()
+    for k in sd:
+        if k == "backbone.patch_embed.proj.bias":
+            assert torch.equal(after[k], sd[k] + 2.0)
+        elif k.startswith("backbone."):
+            assert torch.equal(after[k], sd[k]), k
+        elif k in head:
+            assert torch.equal(after[k], sd[k] + 1.0), k
+        else:
+            assert torch.equal(after[k], before[k]), k          # untouched
+    assert all(not k.startswith("backbone.") for k in rep["missing_keys"])
+
+
+def test_legacy_key_shims(tmp_path):
+    """pre-v2 checkpoints: pixel-decoder weights at the head's top level (oneformer_head.py:26-48) and `static_query`
+    (oneformer_transformer_decoder.py:231-252) are renamed on load."""
+    from uenc.checkpoint import DetectionCheckpointer, write_wrapper
+    m, fill = _small_model()
+    fill.fill_module(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    legacy = {}
+    for k, v in sd.items():
+        if k.startswith("sem_seg_head.pixel_decoder."):
+            legacy["sem_seg_head." + k[len("sem_seg_head.pixel_decoder."):]] = v
+        else:
+            legacy[k] = v
+    path = str(tmp_path / "legacy.pkl")
+    write_wrapper(path, legacy)
+    m2, _ = _small_model()
+    rep = DetectionCheckpointer(m2).load(path)
+    assert rep["missing_keys"] == [] and rep["unexpected_keys"] == []
+    _same(dict(m2.state_dict()), sd)
+    # static_query -> query_feat: the renamed key is what load_state_dict then sees (this model has no such parameter: reported)
+    dec = m2.sem_seg_head.predictor
+    s2 = dict(dec.state_dict())
+    s2["static_query.weight"] = torch.zeros(3)
+    res = dec.load_state_dict(s2, strict=False)
+    assert res.unexpected_keys == ["query_feat.weight"]
+
+
+def test_checkpoint_files_are_data_not_code(tmp_path):
+    """A pickle that would run a command when unpickled is refused, before anything executes."""
+    from uenc.checkpoint import read_checkpoint
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    bad = str(tmp_path / "bad.pkl")
+    with open(bad, "wb") as f:
+        pickle.dump({"model": {"w": Evil()}, "__author__": "x", "matching_heuristics": False}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        read_checkpoint(bad)
+    assert not marker.exists()
+    bad_pth = str(tmp_path / "bad.pth")
+    torch.save({"model": {"w": Evil()}}, bad_pth)
+    with pytest.raises(Exception):
+        read_checkpoint(bad_pth)
+    assert not marker.exists()

@@ -346,3 +346,40 @@ def test_predictor_configs0_swin_t_512x1024(U):
     e = res["exact"]
     assert e["pred_logits"] < 1e-3 and e["sem_seg"] < 1e-3 and e["sem_argmax_agreement"] > 0.999, res
     assert res["bf16"]["sem_argmax_agreement"] > 0.9, res
+
+
+def test_checkpoint_round_trip_identical_outputs(U, tmp_path):
+    """Checkpoint ingest on the HIP path: product weights -> Detectron2 wrapper .pkl -> a FRESH model through
+    DetectionCheckpointer: bit-identical outputs; the same file read as the oracle's state dict: exact-mode parity."""
+    from oracle import torch_ref as T
+    from uenc import ops
+    from uenc.checkpoint import DetectionCheckpointer, read_checkpoint, write_wrapper
+    from test_exact_gpu import _small_model
+    g = load_golden("model_fwd_bwd")
+    batch = [{"left_image": g["img0"].float(), "task": "The task is panoptic", "type": "segmentation"}]
+    a = _small_model()
+    with torch.no_grad():
+        for p in a.parameters():                     # not the name-hashed fill: weights only this file carries
+            p.add_(0.01 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(p.device))
+    path = str(tmp_path / "model_final.pkl")
+    write_wrapper(path, a.state_dict())
+    b = _small_model()
+    rep = DetectionCheckpointer(b).load(path)
+    assert rep["missing_keys"] == [] and rep["unexpected_keys"] == []
+    with torch.no_grad():
+        oa, _ = a.forward_features(batch)
+        ob, _ = b.forward_features(batch)
+    assert torch.equal(oa["pred_logits"], ob["pred_logits"]) and torch.equal(oa["pred_masks"], ob["pred_masks"])
+    sd = {k: v.float() for k, v in read_checkpoint(path)["model"].items()}
+    ocfg = T.ModelCfg(swin=T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7))
+    with torch.no_grad():
+        oref = T.oneformer_forward([{"left_image": batch[0]["left_image"], "task": batch[0]["task"]}], sd, ocfg, upsample=False)
+    ops.set_exact(True)
+    try:
+        with torch.no_grad():
+            oe, _ = b.forward_features(batch)
+    finally:
+        ops.set_exact(False)
+    r = (rel(oe["pred_logits"], oref["pred_logits"]), rel(oe["pred_masks"], oref["pred_masks"]))
+    record_parity("checkpoint/round_trip_vs_oracle_exact", pred_logits=r[0], pred_masks=r[1])
+    assert r[0] < 1e-3 and r[1] < 1e-3, r

@@ -16,6 +16,9 @@ class DefaultPredictor:
         self.cfg = cfg.clone()
         self.model = build_model(self.cfg)
         self.model.eval()
+        if getattr(cfg.MODEL, "WEIGHTS", ""):               # demo/defaults.py:56-57
+            from .checkpoint import DetectionCheckpointer
+            DetectionCheckpointer(self.model).load(cfg.MODEL.WEIGHTS)
         self.min_size, self.max_size = cfg.INPUT.SEG_MIN_SIZE_TEST, cfg.INPUT.SEG_MAX_SIZE_TEST
 
     def _resize(self, img):  # (3, H, W) float
