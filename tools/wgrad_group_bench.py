@@ -38,7 +38,7 @@ import os
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]      # UENC_GEMM_VARIANT values to A/B (bit 256: two-stage TN loop)
 for tag, M, C in [("s1", 262144, 192), ("s2", 65536, 384), ("s3x6", 16384, 768), ("s4", 4096, 1536)]:
     probs = build(M, C, 6 if tag == 's3x6' else 2)
-    for tile, tokens in [(128, 4096), (256, 8192), (256, 4096)]:
+    for tile, tokens in [(128, 4096), (256, 8192), (256, 16384)]:
         d, fl = descs(probs, tile, tokens)
         row = []
         for v in variants:

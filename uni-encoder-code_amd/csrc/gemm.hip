@@ -891,6 +891,7 @@ struct GemmTN {
     int tiles_n, tiles_k;
     int mlen;  // tokens per split (multiple of BK)
     int store; // tnbig only: 1 = the tile is stored (dW = ..., db = ...: single split, no prior zeroing), 0 = added atomically
+    int variant;   // debug A/B switch (UENC_GEMM_VARIANT)
 };
 
 __device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
@@ -1221,9 +1222,282 @@ __device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit
     }
 }
 
+// Deep-prefetch form of the same tile (the default): one 64-token stage ahead of the MFMAs (above) leaves 0.86 us -- the stage's
+// 8.4 MFLOP at the CU's peak -- for a DMA that takes 1-2.5 us under load, so the loop ran at the memory LATENCY (~0.7 PFLOP/s
+// whatever the item order or the cache level the panels came from).  Here the ring holds four 32-token stages (one MFMA k-step
+// each, same 128 / 64 KB), the DMA stream runs three stages = 96 tokens ahead, waits are counted (`vmcnt(8)` leaves two stages
+// in flight) and the barrier is a raw s_barrier that does not drain the DMA queue: a stage is read only after the issuing
+// waves' counted wait AND the barrier every wave passes after it; its slot is refilled one barrier after its last read.
+template <int TILE>
+__device__ __forceinline__ void tnbig_body_deep(const GemmTN& p, int tile, int msplit) {
+    constexpr int NTHR = TILE * 2, NWN = TILE / 64, WKT = (TILE == 256 ? 8 : 4);
+    constexpr int SR = 32, NS = 4, D = NS - 1;                                           // rows per stage, ring slots, stages in flight
+    constexpr int IMG = SR * TILE * 2;                                                   // bytes of one operand image
+    constexpr int RPI = NTHR * 16 / (TILE * 2);                                          // rows filled per DMA instruction (16)
+    constexpr int CPR = TILE / 8;                                                        // 16-byte slots per row
+    static_assert(RPI == 16, "two DMA instructions per operand and stage");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                 // NS stages x (dY + X)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave / NWN, wn = wave % NWN;
+    const int ntile = tile / p.tiles_k, ktile = tile - ntile * p.tiles_k;
+    const int n0 = ntile * TILE, k0 = ktile * TILE;
+    const int mbeg = msplit * p.mlen;
+    const int mend = min(p.M, mbeg + p.mlen);
+    const int nst = (mend - mbeg) / SR;
+
+    f32x4 acc[WKT][4];
+#pragma unroll
+    for (int i = 0; i < WKT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16* ysrc[2];
+    const bf16* xsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = q * RPI + t / CPR, P = t % CPR;
+        const int piece = (P >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2));
+        const int col = piece * 16 + (P & 1) * 8;
+        ysrc[q] = (const bf16*)p.dY + (long)(mbeg + row) * p.ldy + min(n0 + col, p.N - 8);
+        xsrc[q] = (const bf16*)p.X + (long)(mbeg + row) * p.ldx + min(k0 + col, p.K - 8);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue = [&](int st) {
+        unsigned char* Ys = smem + (st & (NS - 1)) * (2 * IMG);
+        unsigned char* Xs = Ys + IMG;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds(ysrc[q] + (long)st * SR * p.ldy, (lds_void*)(Ys + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xsrc[q] + (long)st * SR * p.ldx, (lds_void*)(Xs + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    const bool do_db = (p.db != nullptr) && (ktile == 0);
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < nst) issue(i);
+    for (int st = 0; st < nst; ++st) {
+        // stage st has landed (this wave's pieces) once at most the min(D - 1, stages after st) younger stages are outstanding
+        wait_vmcnt_upto8(4 * min(D - 1, nst - 1 - st));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                        // ... and everyone's; every wave is also past its reads of stage st - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + D < nst) issue(st + D);                     // into the slot of stage st - 1
+        const unsigned char* Ys = smem + (st & (NS - 1)) * (2 * IMG);
+        const unsigned char* Xs = Ys + IMG;
+        bf16x8 kf[WKT], nf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nf[j] = tn_frag<TILE>(Ys, 0, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < WKT; ++i) kf[i] = tn_frag<TILE>(Xs, 0, wk * (WKT * 16) + i * 16, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < WKT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(kf[i], nf[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (do_db) {
+            const int c8 = (t % CPR) * 8, rg = t / CPR;       // 16 row groups
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const bf16x8 v = *(const bf16x8*)(Ys + tn_off<TILE>(rg + 16 * rr, c8));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bsum[c] += (float)v[c];
+            }
+        }
+    }
+
+    float* T = (float*)smem;
+    constexpr int LDT = TILE + 4;
+    if (do_db) {            // reduce the 16 row-groups through LDS, then one atomic per column
+        __syncthreads();
+        const int c8 = (t % CPR) * 8, rg = t / CPR;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) T[rg * TILE + c8 + c] = bsum[c];
+        __syncthreads();
+        if (t < TILE) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
+            if (n0 + t < p.N) { if (p.store) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
+        }
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int ps = 0; ps < NWN; ++ps) {
+        __syncthreads();
+        if (wn == ps) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < WKT; ++i) *(f32x4*)(T + (j * 16 + fr) * LDT + wk * (WKT * 16) + i * 16 + 4 * fg) = acc[i][j];
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += NTHR / 64) {
+            const int n = n0 + ps * 64 + row;
+            if (n >= p.N) break;
+#pragma unroll
+            for (int q = 0; q < TILE / 64; ++q) {
+                const int k = k0 + lane + 64 * q;
+                if (k < p.K) {
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                }
+            }
+        }
+    }
+}
+
+// Hand-scheduled form of the deep-prefetch loop.  In tnbig_body_deep hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the
+// first transposing LDS read of every stage (an LDS read with a memory operand waits for ALL LDS-DMA in flight) and
+// `lgkmcnt(0)` in front of the first MFMA: the DMA ring is drained every 32 tokens and no read overlaps an MFMA -- it measured
+// 10-30 % SLOWER than the two-stage loop.  Here the fragment reads are inline asm (invisible to the waitcnt pass), issued at
+// most 14 deep (lgkmcnt is a 4-bit counter), each group of four MFMAs waits with a counted lgkmcnt for exactly the fragment it
+// consumes, and the bias gradient comes from four extra MFMAs against an all-ones fragment instead of LDS row sums.
+template <int ROW4>
+__device__ __forceinline__ void ds_tr_pair(bf16x8& f, unsigned addr) {
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(ROW4) : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+}
+
+template <int TILE>
+__device__ __forceinline__ void tnbig_body_asm(const GemmTN& p, int tile, int msplit) {
+    constexpr int NTHR = TILE * 2, NWN = TILE / 64, WKT = (TILE == 256 ? 8 : 4);
+    constexpr int SR = 32, NS = 4, D = NS - 1;
+    constexpr int IMG = SR * TILE * 2;
+    constexpr int RPI = NTHR * 16 / (TILE * 2);
+    constexpr int CPR = TILE / 8;
+    constexpr int ROW4 = 4 * TILE * 2;                                                   // byte distance of rows r and r + 4
+    static_assert(RPI == 16, "two DMA instructions per operand and stage");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave / NWN, wn = wave % NWN;
+    const int ntile = tile / p.tiles_k, ktile = tile - ntile * p.tiles_k;
+    const int n0 = ntile * TILE, k0 = ktile * TILE;
+    const int mbeg = msplit * p.mlen;
+    const int mend = min(p.M, mbeg + p.mlen);
+    const int nst = (mend - mbeg) / SR;
+
+    f32x4 acc[WKT][4];
+#pragma unroll
+    for (int i = 0; i < WKT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    const bf16* ysrc[2];
+    const bf16* xsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = q * RPI + t / CPR, P = t % CPR;
+        const int piece = (P >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2));
+        const int col = piece * 16 + (P & 1) * 8;
+        ysrc[q] = (const bf16*)p.dY + (long)(mbeg + row) * p.ldy + min(n0 + col, p.N - 8);
+        xsrc[q] = (const bf16*)p.X + (long)(mbeg + row) * p.ldx + min(k0 + col, p.K - 8);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue = [&](int st) {
+        unsigned char* Ys = smem + (st & (NS - 1)) * (2 * IMG);
+        unsigned char* Xs = Ys + IMG;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds(ysrc[q] + (long)st * SR * p.ldy, (lds_void*)(Ys + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xsrc[q] + (long)st * SR * p.ldx, (lds_void*)(Xs + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    // LDS byte addresses (relative to a stage's dY image) of this lane's first read of every fragment; the second read is ROW4 further
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned anf[4], akf[WKT];
+    {
+        const int fg = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+        const int ra = 8 * fg + q4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) anf[j] = lds0 + tn_off<TILE>(ra, wn * 64 + j * 16 + 4 * p4);
+#pragma unroll
+        for (int i = 0; i < WKT; ++i) akf[i] = lds0 + IMG + tn_off<TILE>(ra, wk * (WKT * 16) + i * 16 + 4 * p4);
+    }
+    const bool do_db = (p.db != nullptr) && (ktile == 0) && (wk == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < nst) issue(i);
+    for (int st = 0; st < nst; ++st) {
+        wait_vmcnt_upto8(4 * min(D - 1, nst - 1 - st));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + D < nst) issue(st + D);
+        const unsigned so = (unsigned)((st & (NS - 1)) * (2 * IMG));
+        bf16x8 kf[WKT], nf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ds_tr_pair<ROW4>(nf[j], anf[j] + so);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ds_tr_pair<ROW4>(kf[i], akf[i] + so);
+#pragma unroll
+        for (int i = 0; i < WKT; ++i) {
+            // reads issued so far: nf + kf[0 .. min(i + 2, WKT - 1)]; kf[i] is complete once at most 2 * (min(i + 2, WKT - 1) - i) pairs remain
+            if (i + 2 < WKT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (i + 1 < WKT) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(kf[i], nf[j], acc[i][j]);
+            if (i + 3 < WKT) ds_tr_pair<ROW4>(kf[i + 3], akf[i + 3] + so);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_db) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accb[j] = mfma16(ones, nf[j], accb[j]);
+        }
+    }
+
+    float* T = (float*)smem;
+    constexpr int LDT = TILE + 4;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (do_db && fg == 0) {       // accb[j][r] = sum_m dY[m][n = wn * 64 + j * 16 + fr] for every r: the column sums, once per column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fr;
+            if (n < p.N) { if (p.store) p.db[n] = accb[j][0]; else atomicAdd(p.db + n, accb[j][0]); }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NWN; ++ps) {
+        __syncthreads();
+        if (wn == ps) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < WKT; ++i) *(f32x4*)(T + (j * 16 + fr) * LDT + wk * (WKT * 16) + i * 16 + 4 * fg) = acc[i][j];
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += NTHR / 64) {
+            const int n = n0 + ps * 64 + row;
+            if (n >= p.N) break;
+#pragma unroll
+            for (int q = 0; q < TILE / 64; ++q) {
+                const int k = k0 + lane + 64 * q;
+                if (k < p.K) {
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                }
+            }
+        }
+    }
+}
+
 template <int TILE>
 __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_kernel(GemmTN p) {
-    tnbig_body<TILE>(p, blockIdx.x, blockIdx.y);
+    if (p.variant & 2048) tnbig_body<TILE>(p, blockIdx.x, blockIdx.y);      // bit 2048: the round-1 main loop, for A/B
+    else if (p.variant & 4096) tnbig_body_deep<TILE>(p, blockIdx.x, blockIdx.y);   // bit 4096: deep ring, compiler-scheduled reads
+    else tnbig_body_asm<TILE>(p, blockIdx.x, blockIdx.y);
 }
 
 // Grouped form: ONE launch computes many weight gradients.  The backward of a layer leaves 4 small-output wgrad GEMMs
@@ -1239,9 +1513,21 @@ struct TnGroupDesc {
     int mlen, nsplit, item_begin, store;
 };
 
-template <int TILE>
-__global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGroupDesc* __restrict__ table, int n) {
-    const int item = blockIdx.x;
+// Item order (XCD_WINDOWS): what shares operand panels must run on ONE XCD at the same time, or every tile re-fetches its
+// dY / X panels from the fabric (measured round 1: 44 GB per step against ~19 GB read once).  Logical items are ordered
+// (descriptor, token split, tile) with the tile fastest, so W consecutive items -- W = the workgroups an XCD runs at once -- are
+// the tiles of one weight over the SAME token range: together they read each 64-token panel piece once into the XCD's L2.
+// Hardware block b runs on XCD slot b % 8 as that slot's (b / 8)-th block: window c of the logical list goes to slot c % 8.
+// Placement is for speed only (any mapping gives the same sums).
+template <int TILE, bool XCD_WINDOWS>
+__global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGroupDesc* __restrict__ table, int n, int total, int deep) {
+    int item = blockIdx.x;
+    if (XCD_WINDOWS) {
+        constexpr int WIN = TILE == 256 ? 32 : 64;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        item = ((j / WIN) * 8 + x) * WIN + (j % WIN);
+        if (item >= total) return;
+    }
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1251,9 +1537,18 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
     GemmTN p;
     p.dY = d.dY; p.dy_f32 = 0; p.ldy = d.ldy; p.X = d.X; p.x_f32 = 0; p.ldx = d.ldx;
     p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.store && d.nsplit == 1;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.store && d.nsplit == 1; p.variant = 0;
     const int local = item - d.item_begin;
-    tnbig_body<TILE>(p, local / d.nsplit, local % d.nsplit);
+    int tile, msplit;
+    if (XCD_WINDOWS) {
+        const int ntiles = ((d.N + TILE - 1) / TILE) * d.tiles_k;
+        tile = local % ntiles; msplit = local / ntiles;
+    } else {
+        tile = local / d.nsplit; msplit = local % d.nsplit;
+    }
+    if (deep == 2) tnbig_body_asm<TILE>(p, tile, msplit);
+    else if (deep == 1) tnbig_body_deep<TILE>(p, tile, msplit);
+    else tnbig_body<TILE>(p, tile, msplit);
 }
 
 // table: n descriptors (device memory) of 88 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, item_begin, store}:
@@ -1266,20 +1561,29 @@ extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, i
     static_assert(sizeof(TnGroupDesc) == 88, "descriptor layout is part of the ABI");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_tnbig_grouped_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256 * 2);
-        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_tnbig_grouped_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2);
-        if (e1 != hipSuccess) return (int)e1;
-        if (e2 != hipSuccess) return (int)e2;
+        const void* fns[4] = {(const void*)gemm_tnbig_grouped_kernel<256, true>, (const void*)gemm_tnbig_grouped_kernel<256, false>,
+                              (const void*)gemm_tnbig_grouped_kernel<128, true>, (const void*)gemm_tnbig_grouped_kernel<128, false>};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * (i < 2 ? 256 : 128) * 2);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     const bool prof = uenc_prof_on();
     if (prof) uenc_prof_begin(UENC_PROF_GEMM_TN, flops, stream);          // flops: 2 * sum(M N K), for the profiler only
-    if (tile == 256)
-        hipLaunchKernelGGL(gemm_tnbig_grouped_kernel<256>, dim3((unsigned)total_items), dim3(512), 4 * 64 * 256 * 2, stream,
-                           (const TnGroupDesc*)table, n);
-    else
-        hipLaunchKernelGGL(gemm_tnbig_grouped_kernel<128>, dim3((unsigned)total_items), dim3(256), 4 * 64 * 128 * 2, stream,
-                           (const TnGroupDesc*)table, n);
+    const char* ev = getenv("UENC_GEMM_VARIANT");
+    const bool windows = !(ev && (atoi(ev) & 512));                       // bit 512: the round-1 item order (tile-major, split fastest), for A/B
+    const int evv = ev ? atoi(ev) : 0;
+    const int deep = (evv & 2048) ? 0 : (evv & 4096) ? 1 : 2;             // bit 2048: the round-1 main loop; bit 4096: deep ring with compiler-scheduled reads
+    const int win = 8 * (tile == 256 ? 32 : 64);
+    const unsigned grid = windows ? (unsigned)((total_items + win - 1) / win * win) : (unsigned)total_items;
+    if (tile == 256) {
+        if (windows) hipLaunchKernelGGL((gemm_tnbig_grouped_kernel<256, true>), dim3(grid), dim3(512), 4 * 64 * 256 * 2, stream, (const TnGroupDesc*)table, n, total_items, deep);
+        else hipLaunchKernelGGL((gemm_tnbig_grouped_kernel<256, false>), dim3(grid), dim3(512), 4 * 64 * 256 * 2, stream, (const TnGroupDesc*)table, n, total_items, deep);
+    } else {
+        if (windows) hipLaunchKernelGGL((gemm_tnbig_grouped_kernel<128, true>), dim3(grid), dim3(256), 4 * 64 * 128 * 2, stream, (const TnGroupDesc*)table, n, total_items, deep);
+        else hipLaunchKernelGGL((gemm_tnbig_grouped_kernel<128, false>), dim3(grid), dim3(256), 4 * 64 * 128 * 2, stream, (const TnGroupDesc*)table, n, total_items, deep);
+    }
     if (prof) uenc_prof_end(stream);
     UENC_LAUNCH_RET();
 }
@@ -1318,6 +1622,7 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     GemmTN p;
     p.dY = dY; p.dy_f32 = (dy_dtype == UENC_F32); p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
     p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K; p.store = 0;
+    { const char* e0 = getenv("UENC_GEMM_VARIANT"); p.variant = e0 ? atoi(e0) : 0; }
     // LDS-DMA paths: bf16 operands, whole 64-token stages.  256x256 tiles when the output has >= 20 of them (every split
     // of the token range costs a 256 KB atomic burst per tile, so splits are capped at 8); else 128x128 tiles, whose
     // outputs are small enough to split the token range much further.
