@@ -39,6 +39,7 @@ struct GemmNT {
     int klen;      // K elements handled by one split (multiple of BK); == K rounded up when splitk == 1
     int atomic;    // fp32 atomicAdd into C (split-K or accumulate)
     int variant;   // debug A/B switch
+    int persist;   // gemm_nt256_kernel: the grid is smaller than the tile count, workgroups walk tile positions
     float alpha;
     long part_stride;     // > 0: split-K with STORED partials: split y writes its tile to C + y * part_stride (fp32 elements), no atomics
     int splits;           // gridDim.y
@@ -417,9 +418,21 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (A 32 KB + W 32 KB)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Persistent form (p.persist, launches with more tiles than CUs): a workgroup walks the tile positions blockIdx.x,
+    // blockIdx.x + gridDim.x, ... (the positions in-order dispatch of one workgroup per tile would have given this CU; gridDim.x is a
+    // multiple of 8, so a workgroup stays on the XCD chunk xcd_remap gives its slot).  The next tile's first six half-tile DMAs are
+    // issued BEFORE the epilogue of the current tile when that epilogue leaves the ring alone (bf16 results), else right after it:
+    // their latency, the workgroup turn-around and the drain of the result stores then overlap work instead of following it.
+    const int ntiles_all = p.tiles_m * p.tiles_n;
+    int pos = blockIdx.x;
+    bool prefetched = false;
+    const bf16* src[4][2];              // [A0, B0, B1, A1][q]: DMA instruction q of this thread (row L >> 3, slot L & 7, L = q * 512 + t)
+    for (;;) {
+    const int tile = xcd_remap(pos, ntiles_all);
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
     const int m0 = mt * BM2, n0 = nt * BN2;
+    const int pos_next = pos + (int)gridDim.x;
+    const bool has_next = p.persist && pos_next < ntiles_all;
     // split-K (EPI_NONE, fp32 C, pre-zeroed or accumulated into): blockIdx.y owns k-tiles [kt0, kt0 + nkt), adds its tile atomically
     // (or, with part_stride > 0, stores it as partial sum number blockIdx.y: summed by the caller)
     const int kt0 = blockIdx.y * (p.klen / BK);
@@ -444,17 +457,19 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
         // other's LDS reads and DMA issue.  The DMA stream runs 6 half-tiles ahead of the reads (half-tile u = 4 T + {A0,B0,B1,A1}; phase
         // s issues u = s + 6 into the slot read last two or three phases ago) and `vmcnt(8)` after the issue leaves four of them in
         // flight: u <= s + 2 has landed in this wave, and in all waves after the next barrier pair, i.e. for the reads of phase s + 1.
-        const bf16* src[4][2];              // [A0, B0, B1, A1][q]: DMA instruction q of this thread (row L >> 3, slot L & 7, L = q * 512 + t)
+        auto set_src = [&](int mm0, int nn0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int lr = q * 64 + (t >> 3), slot = t & 7;
-            const int chunk = slot ^ ((lr >> 1) & 7);
-            const int ra = (lr >> 6) * 128 + (lr & 63), rb = (lr >> 5) * 64 + (lr & 31);
-            src[0][q] = (const bf16*)p.A + (long)min(m0 + ra, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
-            src[3][q] = (const bf16*)p.A + (long)min(m0 + ra + 64, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
-            src[1][q] = p.W + (long)min(n0 + rb, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
-            src[2][q] = p.W + (long)min(n0 + rb + 32, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
-        }
+            for (int q = 0; q < 2; ++q) {
+                const int lr = q * 64 + (t >> 3), slot = t & 7;
+                const int chunk = slot ^ ((lr >> 1) & 7);
+                const int ra = (lr >> 6) * 128 + (lr & 63), rb = (lr >> 5) * 64 + (lr & 31);
+                src[0][q] = (const bf16*)p.A + (long)min(mm0 + ra, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
+                src[3][q] = (const bf16*)p.A + (long)min(mm0 + ra + 64, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
+                src[1][q] = p.W + (long)min(nn0 + rb, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
+                src[2][q] = p.W + (long)min(nn0 + rb + 32, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
+            }
+        };
+        if (!prefetched) set_src(m0, n0);
         // LDS offsets of the half-tiles inside a k-tile buffer, by sequence position o = 0..3 (A0, B0, B1, A1)
         const int U = 4 * nkt;
         auto issue = [&](int o, int tile) {          // o compile-time after inlining
@@ -464,8 +479,13 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
                 __builtin_amdgcn_global_load_lds(src[o][q] + (long)tile * BK, (lds_void*)(dst + q * 8192), 16, 0, 0);
         };
         // prologue: half-tiles 0..5 (k-tile 0 and A0, B0 of k-tile 1); A0, B0 of k-tile 0 must have landed everywhere before phase 0
-        issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
-        if (U > 4) { issue(0, 1); issue(1, 1); }
+        auto prologue = [&]() {
+            issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+            if (U > 4) { issue(0, 1); issue(1, 1); }
+        };
+        if (!prefetched) prologue();
+        // (a prefetched prologue is followed by the previous tile's result stores: they are younger, so this wait also covers them
+        // up to the last 8 -- conservative, never early)
         wait_vmcnt_upto8(U > 4 ? 8 : 4);
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();             // the stagger: group 1 runs one barrier behind group 0
@@ -562,6 +582,15 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();             // group 0 waits for group 1's last phase
+        prefetched = false;
+        if (has_next && !OUT_F32 && !(p.variant & 32768)) {     // the register-direct epilogue does not touch LDS: start the next tile's loads now
+            const int tile2 = xcd_remap(pos_next, ntiles_all);
+            const int mt2 = tile2 / p.tiles_n;
+            set_src(mt2 * BM2, (tile2 - mt2 * p.tiles_n) * BN2);
+            __builtin_amdgcn_sched_barrier(0);
+            prologue();
+            prefetched = true;
+        }
     } else {
         // DMA geometry: instruction q of a thread fills LDS chunk index L = q * 512 + t  (row L >> 3, slot L & 7)
         const bf16* asrc[4];
@@ -606,6 +635,109 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     }
 
     // epilogue: four passes of 64 rows through a padded fp32 LDS tile [64][260]; then 8 columns per thread
+    if (p.variant & 16384) {                 // timing experiment: no epilogue at all (keeps the accumulators alive)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
+        if (!has_next) return;
+        pos = pos_next;
+        continue;
+    }
+    if (!OUT_F32 && !(p.variant & 32768)) {
+        // ---- register-direct epilogue (bf16 results) ----
+        // acc[i][j][r] = C[m0 + wm*128 + j*16 + fr][n0 + wn*64 + i*16 + 4*fg + r]: a lane owns 4 consecutive columns of one row per
+        // (i, j) and the four lanes fr, fr+16, fr+32, fr+48 own 16 consecutive ones.  The 8-byte bf16 pieces are widened first: one
+        // v_permlane16_swap between the lanes 16 apart trades the second half of column group i against the first half of group
+        // i+1, after which a lane holds 8 consecutive columns = one 16-byte store, in 64-byte runs per row; the saved bf16
+        // activation of the dGELU / dReLU epilogues is read the same way.  No LDS, no barriers: the LDS-staged form below takes 6 us
+        // of a 27 us K = 768 tile (four passes, eight barriers, half the waves idle in each); measured on the workload's shapes the
+        // direct form is 5-13 % faster per launch for bf16 results.  fp32 results keep the staged form: its 1 KB runs per row beat
+        // 64-byte (direct) and 256-byte (per-wave patches) runs by 7-20 % on the HBM-bound shapes.  Bit 32768 of UENC_GEMM_VARIANT
+        // selects the staged form everywhere (A/B).
+        const int mrow = m0 + wm * 128 + fr, ncol = n0 + wn * 64 + 4 * fg;
+        float bv4[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = ncol + i * 16;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias != nullptr && n < p.N && blockIdx.y == 0) b = *(const float4*)(p.bias + n);
+            bv4[i][0] = b.x; bv4[i][1] = b.y; bv4[i][2] = b.z; bv4[i][3] = b.w;
+        }
+        // column at which this lane's 16-byte bf16 store of pair pr (column groups 2 pr, 2 pr + 1) starts
+        const int odd = fg & 1;
+        const int n16[2] = {n0 + wn * 64 + (0 + odd) * 16 + 4 * (fg - odd), n0 + wn * 64 + (2 + odd) * 16 + 4 * (fg - odd)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = mrow + j * 16;
+            const bool row_ok = m < p.M;
+            float v[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] = (acc[i][j][r] + bv4[i][r]) * p.alpha;
+            u32x2 pre2[4];
+            if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { q[r] = (bf16)v[i][r]; v[i][r] = gelu_f(v[i][r]); }
+                    pre2[i] = *(const u32x2*)&q;
+                }
+            } else if (EPI == EPI_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(v[i][r], 0.f);
+            } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
+                // the saved bf16 activation is read in the widened layout (16 bytes per lane) and brought back to the accumulator
+                // layout by the same swap (an involution)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    u32x4 x = {0u, 0u, 0u, 0u};
+                    if (row_ok && n16[pr] < p.N) x = *(const u32x4*)((const bf16*)p.aux + (long)m * p.ldaux + n16[pr]);
+                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(x[0], x[2], false, false);
+                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(x[1], x[3], false, false);
+                    const u32x2 sa = {lo[0], hi[0]}, sb = {lo[1], hi[1]};
+                    const bf16x4 s0 = *(const bf16x4*)&sa, s1 = *(const bf16x4*)&sb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[2 * pr][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr][r] * dgelu_f((float)s0[r]) : (((float)s0[r] > 0.f) ? v[2 * pr][r] : 0.f);
+                        v[2 * pr + 1][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr + 1][r] * dgelu_f((float)s1[r]) : (((float)s1[r] > 0.f) ? v[2 * pr + 1][r] : 0.f);
+                    }
+                }
+            }
+            {
+                u32x2 o2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = (bf16)v[i][r];
+                    o2[i] = *(const u32x2*)&q;
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(o2[2 * pr][0], o2[2 * pr + 1][0], false, false);
+                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(o2[2 * pr][1], o2[2 * pr + 1][1], false, false);
+                    if (row_ok && n16[pr] < p.N) *(u32x4*)((bf16*)p.C + (long)m * p.ldc + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+                }
+            }
+            if (EPI == EPI_GELU && p.aux_out != nullptr) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][0], pre2[2 * pr + 1][0], false, false);
+                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][1], pre2[2 * pr + 1][1], false, false);
+                    if (row_ok && n16[pr] < p.N) *(u32x4*)(p.aux_out + (long)m * p.ldaux_out + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+                }
+            }
+        }
+        if (!has_next) return;
+        pos = pos_next;
+        continue;
+    }
+    const bool skip_stores = (p.variant & 8192) != 0;      // timing experiment: epilogue math + LDS passes, no global stores / aux loads
     float* T = (float*)smem;
     constexpr int LDT = 260;
     const int erow = t >> 5, ecol = (t & 31) * 8;
@@ -640,6 +772,15 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * p.alpha; v[4 + r] = (a1[r] + bv[4 + r]) * p.alpha; }
+            if (skip_stores) {
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) asm volatile("" :: "v"(v[r]));
+                continue;
+            }
             if (EPI == EPI_GELU) {
                 if (p.aux_out != nullptr) {
                     bf16x8 pre;
@@ -692,6 +833,10 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             }
         }
     }
+    if (!has_next) return;
+    __syncthreads();          // the staged epilogue's last reads of the LDS tile precede the next tile's DMA writes
+    pos = pos_next;
+    }
 }
 
 template <int EPI, int OUT_F32, int PIPE>
@@ -703,7 +848,16 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE>), dim3(p.tiles_m * p.tiles_n, p.splits), dim3(T2), 131072, stream, p);
+    // more tiles than CUs: one persistent workgroup per CU walks its tile positions (bit 65536 of UENC_GEMM_VARIANT: one workgroup per tile)
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) ncu = v / 8 * 8;
+        else ncu = 256;
+    }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    p.persist = (PIPE == 1 && p.splits == 1 && ntiles > ncu && !(p.variant & 65536)) ? 1 : 0;
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE>), dim3(p.persist ? ncu : ntiles, p.splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
 }
 
