@@ -84,28 +84,33 @@ def make_cfg(device):
     return cfg
 
 
-class _MeanSquare(torch.autograd.Function):
-    """mean(x^2) as one reduction forward and one scaled copy backward (autograd's pow / mean chain is five
-    full passes over every 157 MB mask tensor)."""
+class _WeightedMeanSquares(torch.autograd.Function):
+    """sum_i w_i * mean(x_i^2) over a list of tensors as ONE autograd node: the norms of all tensors by multi-tensor kernels
+    (torch._foreach_norm), the gradient of each tensor as one scaled copy.  (Per-tensor pow / mean / mul / add chains cost ~130
+    tiny launches per step for the 20 predictions, and autograd's pow-mean chain five passes over every 157 MB mask tensor.)"""
 
     @staticmethod
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.linalg.vector_norm(x.float()).square() / x.numel()
+    def forward(ctx, weights, *xs):
+        ctx.save_for_backward(*xs)
+        norms = torch.stack(torch._foreach_norm([x.detach().float() if x.dtype != torch.float32 else x.detach() for x in xs]))
+        coef = torch.tensor([w / x.numel() for w, x in zip(weights, xs)], dtype=torch.float32).to(norms.device, non_blocking=True)
+        ctx.coef = coef
+        return (norms.square() * coef).sum()
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return x * (g * (2.0 / x.numel())).to(x.dtype)
+        xs = ctx.saved_tensors
+        c = (ctx.coef * (2.0 * g)).unbind()          # one launch for the 20 coefficients
+        return (None,) + tuple(x * ci.to(x.dtype) for x, ci in zip(xs, c))
 
 
 def synthetic_loss(out):
     """mean-square of logits and masks, x0.1 on the nine auxiliary predictions."""
-    ms = _MeanSquare.apply
-    loss = ms(out["pred_logits"]) + ms(out["pred_masks"])
+    xs, ws = [out["pred_logits"], out["pred_masks"]], [1.0, 1.0]
     for a in out["aux_outputs"]:
-        loss = loss + 0.1 * (ms(a["pred_logits"]) + ms(a["pred_masks"]))
-    return loss
+        xs += [a["pred_logits"], a["pred_masks"]]
+        ws += [0.1, 0.1]
+    return _WeightedMeanSquares.apply(ws, *xs)
 
 
 def _cores():

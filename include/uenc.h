@@ -179,13 +179,14 @@ int uenc_relpos_expand(const float* table /* ((2ws-1)^2, nH) */, float* bias_q /
 int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
                          int C, int nH, int ws, int shift, float scale, void* stream);
 /* dqkv (B,H,W,3C) bf16 written.  dS_ws: scratch of uenc_window_attn_bwd_ws_floats() floats (dense per-workgroup sums of
- * dS, overwritten).  dgrads: (nH * (2ws-1)^2 + 3C) fp32, overwritten: the relative-position-table gradient as
- * [head][(2ws-1)^2], then the q | k | v slice of the qkv.bias gradient that flows through padding slots (the zero rows
+ * dS, overwritten).  The two parameter gradients are ACCUMULATED (+=, float atomics) straight into the caller's buffers, i.e.
+ * into attn.relative_position_bias_table.grad and attn.qkv.bias.grad: dtable ((2ws-1)^2, nH) fp32 in the parameter's own
+ * layout; dbias_pad (3C) fp32 = the q | k | v slice of the qkv.bias gradient that flows through padding slots (the zero rows
  * F.pad appends after norm1, swin.py:254, whose q/k/v equal the bias). */
 long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws);
 int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                         const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dgrads, int B,
-                         int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
+                         const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
+                         int B, int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
 
 /* ---- multi-scale deformable attention: the reference's native op ---------------------------------------
  * ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)

@@ -187,11 +187,14 @@ def test_window_attention_fwd_bwd(K, ws, H, W, nH, shift):
     _close(out.view(B, H * W, C), want, 3e-2, 2e-2)
     do = _r(B, H * W, C, seed=4, dtype=torch.bfloat16)
     want.backward(do.float())
-    dqkv, dtab, dpad = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), qb, bq, bk, out, do.view(B, H, W, C), ws, shift, 32 ** -0.5)
+    # the two parameter gradients are ACCUMULATED into the caller's buffers (the parameters' .grad): start them non-zero
+    dtab0, dpad0 = _r((2 * ws - 1) ** 2, nH, seed=5), _r(3 * C, seed=6)
+    dtab, dpad = dtab0.clone(), dpad0.clone()
+    dqkv = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), qb, bq, bk, out, do.view(B, H, W, C), ws, shift, 32 ** -0.5, dtable=dtab, dbias=dpad)
     gs = float(q32.grad.abs().max())
     _close(dqkv.view(B, H * W, 3 * C), q32.grad, 3e-2 * gs, 3e-2)
-    _close(dtab.t(), t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
-    _close(dpad, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)
+    _close(dtab - dtab0, t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
+    _close(dpad - dpad0, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)
 
 
 def test_msdeform_golden(K):

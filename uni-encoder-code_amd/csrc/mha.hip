@@ -58,7 +58,7 @@ __device__ __forceinline__ void stage_rows(unsigned char* img, const bf16* base,
 // ------------------------------------------------------------------------------------------------
 // forward (MODE 0) and dQ (MODE 1): waves own query tiles, loop over the key range
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool DROP>
 __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(MQ + MQ + 4 * KB) * 64];
     unsigned char* Qs = smem;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                         const float e = ok[kt][r] ? fast_exp2(s[kt][r] - mnew) : 0.f;
                         sum += e;                                    // the softmax normaliser is taken BEFORE dropout
                         s[kt][r] = e;
-                        if (p.drop_thresh != 0u)
+                        if (DROP)
                             s[kt][r] = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
                                            ? e * p.inv_keep : 0.f;
                     }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                     for (int r = 0; r < 4; ++r) {
                         const float pr = ok[kt][r] ? fast_exp2(s[kt][r] - lse_q[i]) : 0.f;
                         float dpv = dp[r];
-                        if (p.drop_thresh != 0u)
+                        if (DROP)
                             dpv = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
                                       ? dpv * p.inv_keep : 0.f;
                         s[kt][r] = pr * (dpv - dl_q[i]);
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void mha_combine_kernel(MhaP p, int nslices) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV: a wave owns a 16-key tile of each 64-key block and sweeps all queries
 // ------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
     constexpr int NQB = MQT / 2;     // 32-query blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
                     if (ok && p.mask != nullptr) ok = p.mask[((long)b * p.Lq + qi) * p.mask_rs + key] == 0;
                     const float pr = ok ? fast_exp2(sv[r] * sc - lv[r]) : 0.f;
                     float keepw = 1.0f;
-                    if (p.drop_thresh != 0u && ok)
+                    if (DROP && ok)
                         keepw = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qi) * p.S + key) ? p.inv_keep : 0.f;
                     pt[h2][r] = pr * keepw;
                     dst[h2][r] = pr * (dp[r] * keepw - dv4[r]);
@@ -456,7 +457,8 @@ extern "C" int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, 
         const long parts = (long)B * H * slices * p.nsplit;
         p.ws_m = workspace; p.ws_l = workspace + parts * MQ; p.ws_o = workspace + 2 * parts * MQ;
     }
-    hipLaunchKernelGGL(mha_q_kernel<0>, dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
+    if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<0, true>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((mha_q_kernel<0, false>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
     if (p.nsplit > 1) {
         const long threads = (long)B * H * slices * MQ * 32;
         hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, slices);
@@ -480,13 +482,17 @@ extern "C" int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, 
     p.dq = dq; p.dq_bs = dq_bs; p.dq_rs = dq_rs;
     p.dk = (bf16*)dk; p.dk_bs = dk_bs; p.dk_rs = dk_rs; p.dv = (bf16*)dv; p.dv_bs = dv_bs; p.dv_rs = dv_rs;
     const int slices = (Lq + MQ - 1) / MQ;
-    hipLaunchKernelGGL(mha_q_kernel<1>, dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
+    if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<1, true>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((mha_q_kernel<1, false>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
     const size_t shm = (size_t)slices * MQ * 64 * 2 + 4 * KB * 64 + (size_t)slices * MQ * 8;
     if (shm > 160 * 1024) return UENC_EINVAL;
+    const bool drop = p.drop_thresh != 0u;
     if (shm > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mha_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute(drop ? (const void*)mha_dkdv_kernel<true> : (const void*)mha_dkdv_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(mha_dkdv_kernel, dim3(p.nsplit, B * H), dim3(256), shm, stream, p);
+    if (drop) hipLaunchKernelGGL(mha_dkdv_kernel<true>, dim3(p.nsplit, B * H), dim3(256), shm, stream, p);
+    else hipLaunchKernelGGL(mha_dkdv_kernel<false>, dim3(p.nsplit, B * H), dim3(256), shm, stream, p);
     UENC_LAUNCH_RET();
 }

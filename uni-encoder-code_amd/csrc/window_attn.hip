@@ -44,7 +44,7 @@ struct WAttn {
     const bf16* d_out;      // (B, H, W, C)
     bf16* dqkv;             // (B, H, W, 3C)
     float* dtab_ws;         // (nH * G, NP * NP) dense dS partial per workgroup (overwritten)
-    float* dpad;            // (3C) q|k|v bias gradient that reaches the heads through padding slots (zeroed by the launcher, atomics)
+    float* dpad;            // (3C) q|k|v bias gradient that reaches the heads through padding slots: ADDED (atomics) to the caller's buffer
     int B, H, W, C, nH, ws, shift, Hp, Wp, nWw, nWin, nWinTotal, N;
     float scale;
 };
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restri
             const int key = ky * ws + kx;
             acc += slab[((key >> 4) * 64 + ((key & 15) >> 2) * 16 + fr) * 4 + (key & 3)];
         }
-        if (acc != 0.f) atomicAdd(dtab + (long)head * T1 * T1 + t, acc);
+        if (acc != 0.f) atomicAdd(dtab + (long)t * nH + head, acc);        // the parameter's own layout ((2ws-1)^2, nH), accumulated
     }
 }
 
@@ -610,9 +610,6 @@ static int launch_bwd(const WAttn& p, float* dtab, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int T1 = 2 * p.ws - 1;
-    hipError_t e = hipMemsetAsync(dtab, 0, ((size_t)p.nH * T1 * T1 + 3 * (size_t)p.C) * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
     hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), shm, stream, p, G);
@@ -660,17 +657,16 @@ extern "C" long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int 
 // the q | k | v (3C) slice of the qkv-bias gradient that flows through padding slots.  dS_ws: scratch of
 // uenc_window_attn_bwd_ws_floats() floats.
 extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                                    const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dgrads,
+                                    const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
                                     int B, int H, int W, int C, int nH, int ws, int shift, float scale, hipStream_t stream) {
     WAttn p;
     int rc = fill_params(p, qkv, qkv_bias, bias_q, bias_k, B, H, W, C, nH, ws, shift, scale);
     if (rc != UENC_OK) return rc;
-    UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dS_ws && dgrads);
+    UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dS_ws && dtable && dbias_pad);
     UENC_CHECK_ARG((((uintptr_t)o_saved | (uintptr_t)d_out | (uintptr_t)dqkv | (uintptr_t)dS_ws) & 15) == 0);
-    const int T1 = 2 * ws - 1;
     p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab_ws = dS_ws;
-    p.dpad = dgrads + (long)nH * T1 * T1;
-#define CALL(NT) { rc = launch_bwd<NT>(p, dgrads, stream); if (rc != UENC_OK) return rc; }
+    p.dpad = dbias_pad;
+#define CALL(NT) { rc = launch_bwd<NT>(p, dtable, stream); if (rc != UENC_OK) return rc; }
     WATTN_DISPATCH(wattn_ntiles(ws), CALL)
 #undef CALL
     UENC_LAUNCH_RET();

@@ -75,7 +75,7 @@ _SIGNATURES = {
     "uenc_mha_f32_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_mha_f32_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
                          c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
-    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
 }
 
 

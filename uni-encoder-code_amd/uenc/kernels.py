@@ -379,34 +379,37 @@ def _scratch(tag: str, nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, shift: int, scale: float):
-    """Returns dqkv (B,H,W,3C) bf16, dtab (nH,(2ws-1)^2) fp32, dbias_pad (3C) fp32 (padding-slot share of qkv.bias grad)."""
+def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, shift: int, scale: float,
+                    dtable: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None):
+    """-> dqkv (B,H,W,3C).  The two parameter gradients are ACCUMULATED by the kernels into `dtable` ((2ws-1)^2, nH) fp32 -- the
+    relative-position table's .grad -- and `dbias` (3C) fp32 -- the share of qkv.bias.grad that flows through padding slots; when
+    a buffer is not given (no training) the contribution goes to scratch."""
     B, H, W, C3 = qkv.shape
     C = C3 // 3
     nH = C // 32
+    TT = (2 * ws - 1) ** 2
+    if dtable is None:
+        dtable = _scratch("wattn_dtab", TT * nH * 4, qkv.device).view(torch.float32)[:TT * nH].view(TT, nH)
+    if dbias is None:
+        dbias = _scratch("wattn_dpad", 3 * C * 4, qkv.device).view(torch.float32)[:3 * C]
+    assert dtable.dtype == torch.float32 and dtable.is_contiguous() and tuple(dtable.shape) == (TT, nH)
+    assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == 3 * C
     if EXACT:
         assert qkv.dtype == torch.float32 and d_out.dtype == torch.float32 and d_out.is_contiguous() and d_out.shape == (B, H, W, C)
-        TT = (2 * ws - 1) ** 2
         dqkv = torch.empty_like(qkv)
-        dtable = torch.zeros((TT, nH), dtype=torch.float32, device=qkv.device)
-        dpad = torch.zeros((3 * C,), dtype=torch.float32, device=qkv.device)
         check(lib.uenc_window_attn_f32_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(),
-                                           dtable.data_ptr(), dpad.data_ptr(), B, H, W, C, nH, ws, shift, float(scale), stream_ptr()),
+                                           dtable.data_ptr(), dbias.data_ptr(), B, H, W, C, nH, ws, shift, float(scale), stream_ptr()),
               "window_attn_f32_bwd")
-        return dqkv, dtable.t(), dpad
+        return dqkv
     assert d_out.dtype == torch.bfloat16 and d_out.is_contiguous() and d_out.shape == (B, H, W, C)
     assert o_saved.dtype == torch.bfloat16 and o_saved.is_contiguous()
     dqkv = torch.empty_like(qkv)
-    TT = (2 * ws - 1) ** 2
     nws = int(lib.uenc_window_attn_bwd_ws_floats(B, H, W, nH, ws))
     wsbuf = _scratch("wattn_dS", nws * 4, qkv.device)                    # dense dS partials (internal)
-    grads = torch.empty(nH * TT + 3 * C, dtype=torch.float32, device=qkv.device)
     check(lib.uenc_window_attn_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), bias_k.data_ptr(),
-                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(), grads.data_ptr(),
+                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(), dtable.data_ptr(), dbias.data_ptr(),
                                    B, H, W, C, nH, ws, shift, float(scale), stream_ptr()), "window_attn_bwd")
-    dtab = grads[:nH * TT].view(nH, TT)
-    dpad = grads[nH * TT:]                                              # [q|k|v][head][32]
-    return dqkv, dtab, dpad
+    return dqkv
 
 
 def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.float32):

@@ -319,7 +319,7 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         for b in range(B):
             K.cast_transpose_bf16(mf32[b].detach(), out=mf16_chw[b])
         mes = []                                             # mask embeddings of all heads: their einsums share one autograd node
-        predictions_class, predictions_mask = [], []
+        predictions_class, predictions_mask = [], []         # (predictions_class collects the heads' normalised queries: see below)
         cls, msk, attn_mask = self.forward_prediction_heads(output, (mf16, H4, W4, mes), size_list[0])
         predictions_class.append(cls); predictions_mask.append(msk)
         for i in range(self.num_layers):
@@ -335,6 +335,11 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
                                                                 size_list[(i + 1) % self.num_feature_levels])
             predictions_class.append(cls); predictions_mask.append(msk)
         assert len(predictions_class) == self.num_layers + 1
+        # class logits of ALL heads in one GEMM: nothing inside the loop consumes them (only the mask logits steer the next layer), so
+        # the ten 300 x 20 x 256 launches (+ their padded-N dgrad / wgrad / bias glue in the backward) become one 3000-row launch
+        nq = predictions_class[0].shape[1]
+        allc = ops.linear(torch.cat(predictions_class, 1), self.class_embed.weight, self.class_embed.bias, out_dtype=torch.float32)
+        predictions_class = [allc[:, i * nq:(i + 1) * nq] for i in range(len(predictions_class))]
         # the eager mask logits become differentiable here: one node for all heads (ops.MaskHeadsFn)
         predictions_mask = [m.view(B, -1, H4, W4) for m in ops.mask_heads(mf32, mf16_chw, [m.view(B, -1, H4 * W4) for m in predictions_mask], mes)]
         return {"contrastive_logits": query_class if self.is_train else None,
@@ -344,7 +349,7 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
     def forward_prediction_heads(self, output, mf, attn_mask_target_size):
         mf16, H4, W4, mes = mf
         d = _ln(self.decoder_norm, output)
-        outputs_class = ops.linear(d, self.class_embed.weight, self.class_embed.bias, out_dtype=torch.float32)
+        outputs_class = d                                    # its class logits are computed with all other heads' at the end of forward
         me = self.mask_embed(d, out_dtype=torch.bfloat16).contiguous()
         B, Q, _ = me.shape
         mes.append(me)

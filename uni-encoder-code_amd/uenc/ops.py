@@ -698,13 +698,12 @@ class SwinBlockFn(torch.autograd.Function):
         dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))                                        # (M, C) bf16
         if train:
             _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
-        dqkv, dtab, dpad = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn,
-                                             dattn.view(B, H, W, C), ws, shift, scale)
+        # (the kernels add the relative-position-table gradient and the padding-slot share of the qkv-bias gradient straight into .grad)
+        dqkv = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn, dattn.view(B, H, W, C), ws, shift, scale,
+                                 dtable=grad_buf(table) if train else None, dbias=grad_buf(bqkv) if train else None)
         dqkv2 = dqkv.view(M, 3 * C)
         dxn = K.gemm_nt(dqkv2, CACHE.mat_t(wqkv))
         if train:
-            grad_buf(bqkv).add_(dpad)
-            grad_buf(table).add_(dtab.t())
             _tn(dqkv2, xn, grad_buf(wqkv), grad_buf(bqkv), (wqkv, bqkv))
         tw = []
         dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
