@@ -278,7 +278,7 @@ def main():
 
     def step(b=None):
         buckets.zero_grad()
-        ops.CACHE.refresh()                    # weights change every training step: every bf16 operand copy is re-cast
+        ops.begin_step(fresh_grads=True)       # weights change every training step: every bf16 operand copy is re-cast; grads are zero
         out, images = model.forward_features(b if b is not None else batch)
         with torch.no_grad():                  # reference :255-263, part of the forward it times
             model.upsample_masks(out["pred_masks"], images.tensor.shape[-2:])

@@ -296,6 +296,9 @@ int uenc_prof_enable(int on); /* also resets */
 int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile), 1 gemm_tn*, 4 gemm_nt256 */, double* ms_total, double* flops_total, long* launches);
 /* algorithmic bytes (operands read once + results written once) of the recorded launches of `kind` (gemm_nt kinds). */
 int uenc_prof_collect_bytes(int kind, double* bytes_total);
+/* algorithmic bytes of the NEXT recorded launch whose entry point cannot derive them (the grouped wgrad launches read their
+ * problem sizes from a device table the caller built). */
+int uenc_prof_next_bytes(double bytes);
 
 #ifdef __cplusplus
 }

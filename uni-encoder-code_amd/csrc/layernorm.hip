@@ -192,9 +192,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
     }
     for (long row = wave0; row < p.M; row += nwaves) {
         const float2 st = p.stats[row];
-        float4 d[NV], xh[NV];
+        float4 d[NV], xh[NV], rs[NV];
         float s1 = 0.f, s2 = 0.f;
         const PatchGather pg(MG ? row : 0, MG ? p.mgH : 1, MG ? p.mgW : 1, p.mgC);
+        // the skip-path gradient is fetched together with dy and h: all of a row's loads are in flight at once (issued behind the
+        // row reductions they added a second full memory latency to every row)
+        if (p.dres != nullptr) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + i * 256;
+                if (c < p.C) rs[i] = *(const float4*)(p.dres + row * p.C + c);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane * 4 + i * 256;
@@ -222,10 +231,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd p) {
                 o.y = st.y * (d[i].y - s1 - xh[i].y * s2);
                 o.z = st.y * (d[i].z - s1 - xh[i].z * s2);
                 o.w = st.y * (d[i].w - s1 - xh[i].w * s2);
-                if (p.dres != nullptr) {
-                    const float4 r = *(const float4*)(p.dres + row * p.C + c);
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
+                if (p.dres != nullptr) { o.x += rs[i].x; o.y += rs[i].y; o.z += rs[i].z; o.w += rs[i].w; }
                 if (MG) {
                     if (pg.ok[gseg[i]]) *(float4*)((float*)p.dx + pg.base + goff[i]) = o;       // every map pixel is written exactly once
                 } else {

@@ -55,6 +55,26 @@ __device__ __forceinline__ void stage_rows(unsigned char* img, const bf16* base,
     }
 }
 
+// Block -> (key split, image * H + head).  A head reads 64 bytes of every 512-byte K / V row: heads 2i and 2i + 1 split each
+// 128-byte line.  Blocks are numbered so that the two heads of a pair, for the same image and key range, are CONSECUTIVE blocks
+// of one XCD (hardware block b runs on XCD slot b % 8): they stream the same lines at the same time and the second read of every
+// line is an L2 hit instead of a second trip to the fabric.  (Odd head counts keep the plain order.)  Speed only.
+__device__ __forceinline__ bool mha_decode_block(const MhaP& p, int& split, int& bh) {
+    const int total = p.nsplit * p.B * p.H;
+    if (p.H & 1) {
+        if ((int)blockIdx.x >= total) return false;
+        split = blockIdx.x % p.nsplit; bh = blockIdx.x / p.nsplit;
+        return true;
+    }
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, npair = p.H >> 1;
+    const int u = (j >> 1) * 8 + x;                       // unit = (image, key split, head pair), head pair fastest
+    if (u >= p.nsplit * p.B * npair) return false;
+    const int hp = u % npair, rest = u / npair;
+    split = rest % p.nsplit;
+    bh = (rest / p.nsplit) * p.H + 2 * hp + (j & 1);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward (MODE 0) and dQ (MODE 1): waves own query tiles, loop over the key range
 // ------------------------------------------------------------------------------------------------
@@ -66,7 +86,9 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
     unsigned char* Ks = smem + 2 * MQ * 64;              // 2 stages x 64 rows
     unsigned char* Vs = Ks + 2 * KB * 64;
 
-    const int split = blockIdx.x, bh = blockIdx.y, q0 = blockIdx.z * MQ;
+    int split, bh;
+    if (!mha_decode_block(p, split, bh)) return;
+    const int q0 = blockIdx.z * MQ;
     const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
     const int k_begin = split * p.keys_per_split;
@@ -295,7 +317,8 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
     float* lse = (float*)(Vs + 2 * KB * 64);
     float* delta = lse + nslices * MQ;
 
-    const int split = blockIdx.x, bh = blockIdx.y;
+    int split, bh;
+    if (!mha_decode_block(p, split, bh)) return;
     const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
     const int k_begin = split * p.keys_per_split;
@@ -457,8 +480,8 @@ extern "C" int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, 
         const long parts = (long)B * H * slices * p.nsplit;
         p.ws_m = workspace; p.ws_l = workspace + parts * MQ; p.ws_o = workspace + 2 * parts * MQ;
     }
-    if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<0, true>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((mha_q_kernel<0, false>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
+    if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<0, true>), dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16), 1, slices), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((mha_q_kernel<0, false>), dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16), 1, slices), dim3(256), 0, stream, p);
     if (p.nsplit > 1) {
         const long threads = (long)B * H * slices * MQ * 32;
         hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, slices);
@@ -482,8 +505,8 @@ extern "C" int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, 
     p.dq = dq; p.dq_bs = dq_bs; p.dq_rs = dq_rs;
     p.dk = (bf16*)dk; p.dk_bs = dk_bs; p.dk_rs = dk_rs; p.dv = (bf16*)dv; p.dv_bs = dv_bs; p.dv_rs = dv_rs;
     const int slices = (Lq + MQ - 1) / MQ;
-    if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<1, true>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((mha_q_kernel<1, false>), dim3(p.nsplit, B * H, slices), dim3(256), 0, stream, p);
+    if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<1, true>), dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16), 1, slices), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((mha_q_kernel<1, false>), dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16), 1, slices), dim3(256), 0, stream, p);
     const size_t shm = (size_t)slices * MQ * 64 * 2 + 4 * KB * 64 + (size_t)slices * MQ * 8;
     if (shm > 160 * 1024) return UENC_EINVAL;
     const bool drop = p.drop_thresh != 0u;
@@ -492,7 +515,7 @@ extern "C" int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return (int)e;
     }
-    if (drop) hipLaunchKernelGGL(mha_dkdv_kernel<true>, dim3(p.nsplit, B * H), dim3(256), shm, stream, p);
-    else hipLaunchKernelGGL(mha_dkdv_kernel<false>, dim3(p.nsplit, B * H), dim3(256), shm, stream, p);
+    if (drop) hipLaunchKernelGGL(mha_dkdv_kernel<true>, dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16)), dim3(256), shm, stream, p);
+    else hipLaunchKernelGGL(mha_dkdv_kernel<false>, dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16)), dim3(256), shm, stream, p);
     UENC_LAUNCH_RET();
 }

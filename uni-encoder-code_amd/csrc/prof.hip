@@ -10,6 +10,7 @@
 namespace {
 struct Rec { int kind; double flops, bytes; hipEvent_t e0, e1; };
 bool g_on = false;
+double g_next_bytes = 0.0;      // algorithmic bytes announced for the next recorded launch (uenc_prof_next_bytes)
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_used = 0;
@@ -27,6 +28,8 @@ hipEvent_t get_event() {
 bool uenc_prof_on() { return g_on; }
 
 void uenc_prof_begin(int kind, double flops, hipStream_t stream, double bytes) {
+    if (bytes == 0.0) bytes = g_next_bytes;
+    g_next_bytes = 0.0;
     Rec r{kind, flops, bytes, get_event(), get_event()};
     if (r.e0 == nullptr || r.e1 == nullptr) return;
     (void)hipEventRecord(r.e0, stream);
@@ -35,6 +38,13 @@ void uenc_prof_begin(int kind, double flops, hipStream_t stream, double bytes) {
 
 void uenc_prof_end(hipStream_t stream) {
     if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, stream);
+}
+
+// Grouped launches take their operands from a device-side table: the host that built the table announces the algorithmic
+// bytes of the next launch here (profiling only; ignored while the timers are off).
+extern "C" int uenc_prof_next_bytes(double bytes) {
+    if (g_on) g_next_bytes = bytes;
+    return 0;
 }
 
 extern "C" int uenc_prof_enable(int on) {

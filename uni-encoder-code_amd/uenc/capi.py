@@ -23,6 +23,7 @@ _SIGNATURES = {
     "uenc_prof_enable": [c_i],
     "uenc_prof_collect": [c_i, c_p, c_p, c_p],
     "uenc_prof_collect_bytes": [c_i, c_p],
+    "uenc_prof_next_bytes": [ctypes.c_double],
     "uenc_cast_f32_bf16": [c_p, c_p, c_l, c_p],
     "uenc_cast_transpose_f32_bf16": [c_p, c_p, c_i, c_i, c_p],
     "uenc_cast_multi": [c_p, c_i, c_l, c_p],

@@ -306,7 +306,8 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         if not mf32.is_contiguous():
             mf32 = mf32.contiguous()
         mem = self.pe_layer.tokens(B, H4, W4, dev).contiguous()      # one materialised map: every layer's value projection reuses its bf16 copy
-        key_in = ops.linear(mf32, self.class_input_proj.weight, self.class_input_proj.bias, residual=mem)
+        # (bf16 result: the sum only feeds the two key projections of the class transformer)
+        key_in = ops.linear(mf32, self.class_input_proj.weight, self.class_input_proj.bias, residual=mem, out_dtype=K.adt())
         tgt = t_tok.expand(-1, Q - 1, -1) if self.use_task_norm else torch.zeros_like(qe[:, :-1])
         out_t = self.class_transformer(mem, key_in, qe[:, :-1], tgt)
         output = torch.cat([out_t, t_tok], 1)

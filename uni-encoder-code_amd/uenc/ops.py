@@ -209,9 +209,14 @@ class WgradQueue:
                    ("mlen", "<i4"), ("nsplit", "<i4"), ("item_begin", "<i4"), ("pad", "<i4")]
     # measured on the Swin-L problem sets (tools/wgrad_group_bench.py): many short items beat few long ones (balance, more loads in
     # flight) until the per-item atomic burst shows, around 4k-8k tokens
+    # `fresh` (set by begin_step): every gradient buffer is known to be zero at the start of this step, so the FIRST weight gradient
+    # written to a buffer whose token range is a single item may be STORED instead of added -- plain stores run at ~5 TB/s, the
+    # 256 KB-per-tile float-atomic bursts of the epilogue at the chip's 1.3 TB/s.  Bias gradients stay accumulated (other kernels
+    # add to them too, e.g. the window-attention backward's padding-slot share of qkv.bias).
+    fresh = False
     FLUSH_ITEMS = {256: 4096, 128: 16384}        # ~16 / 32 waves of workgroups per launch (bigger groups measured a little faster;
                                                  # flushing only at the end of backward would stall the gradient all-reduce overlap)
-    TOKENS_PER_ITEM = {256: 8192, 128: 4096}     # token range of one work item (128 / 64 k-steps of 64)
+    TOKENS_PER_ITEM = {256: 16384, 128: 4096}     # token range of one work item (128 / 64 k-steps of 64)
 
     def __init__(self):
         self.pending = {256: [], 128: []}        # tile -> [(desc tuple without item_begin, items, keepalive)]
@@ -221,6 +226,8 @@ class WgradQueue:
         self.notify = []
         self.callback_armed = False
         self.enabled = True
+        self.written = set()                     # data_ptr of gradient buffers that received a contribution this step
+        self.stores = {}                         # data_ptr -> store flag of a queued, not yet launched "store" descriptor
 
     @staticmethod
     def eligible(dy, x, gw) -> bool:
@@ -267,7 +274,7 @@ class WgradQueue:
     def busy(self) -> bool:
         return bool(self.notify or self.items[256] or self.items[128] or self.small_items)
 
-    def add(self, dy, x, gw, gb, notify=()):
+    def add(self, dy, x, gw, gb, notify=(), first=False):
         M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
         # 256 x 256 tiles re-read the operands half as often as 128 x 128 ones; they win unless padding N, K up to 256 wastes too much
         pad = lambda t: (-(-N // t) * t) * (-(-Kd // t) * t)
@@ -277,8 +284,11 @@ class WgradQueue:
         nsplit = -(-M // mlen)
         tiles_k = -(-Kd // tile)
         items = -(-N // tile) * tiles_k * nsplit
+        store = [2 if (self.fresh and nsplit == 1 and first) else 0]      # mutable: a later contribution to the same buffer clears it
+        if store[0]:
+            self.stores[gw.data_ptr()] = store
         self.pending[tile].append(((dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else 0,
-                                    dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, tiles_k, mlen, nsplit), items, (dy, x, gw, gb)))
+                                    dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, tiles_k, mlen, nsplit), items, (dy, x, gw, gb), store))
         self.items[tile] += items
         self.notify.extend(p for p in notify if p is not None)
         self._arm()
@@ -291,13 +301,15 @@ class WgradQueue:
         import numpy as np
         from .capi import check, lib, stream_ptr
         desc = np.zeros(len(descs), dtype=cls._DESC)
-        begin, flops = 0, 0.0
+        begin, flops, nbytes = 0, 0.0, 0.0
         for i, d in enumerate(descs):
             desc[i] = d[:13] + (begin, d[14])
             begin += d[13]
             flops += 2.0 * d[7] * d[8] * d[9]
+            nbytes += 2.0 * d[7] * (d[8] + d[9]) + 4.0 * d[8] * d[9]           # bf16 operands read once + the fp32 gradient written once
         host = torch.from_numpy(desc.view(np.uint8)).pin_memory()
         tab = host.to(device, non_blocking=True)
+        lib.uenc_prof_next_bytes(nbytes)
         check(lib.uenc_gemm_tn_grouped(tab.data_ptr(), len(descs), begin, tile, flops, stream_ptr()), "gemm_tn_grouped")
 
     def _end_of_backward(self):
@@ -311,15 +323,30 @@ class WgradQueue:
         self.items = {256: 0, 128: 0}
         self.small, self.small_items, self.notify = [], 0, []
         self.callback_armed = False
+        self.written = set()
+        self.stores = {}
+        self.fresh = False
+
+    def touch(self, gw) -> bool:
+        """Record a contribution to gradient buffer `gw`; returns True if it is the first of this step.  A queued STORE into the same
+        buffer is turned back into an accumulation (it will run after whatever is written now)."""
+        key = gw.data_ptr()
+        first = key not in self.written
+        self.written.add(key)
+        st = self.stores.pop(key, None)
+        if st is not None:
+            st[0] = 0
+        return first
 
     def flush(self):
         """Launch everything queued (both tile classes), then release the held gradient-ready notifications."""
+        self.stores = {}
         for tile in (256, 128):
             ent = self.pending[tile]
             if not ent:
                 continue
             ent.sort(key=lambda e: -e[0][11])                       # longest token ranges first
-            self.launch(tile, [d + (items, 0) for d, items, _ in ent], ent[0][2][0].device)
+            self.launch(tile, [d + (items, st[0]) for d, items, _, st in ent], ent[0][2][0].device)
             self.pending[tile] = []
             self.items[tile] = 0
         if self.small:
@@ -344,6 +371,15 @@ class WgradQueue:
 WGRADS = WgradQueue()
 
 
+def begin_step(fresh_grads: bool = False):
+    """Start of a training step (after the gradients were zeroed / re-pointed, before the forward): drops whatever a failed backward
+    left queued and re-casts the bf16 operand copies of the updated weights.  fresh_grads=True declares that every gradient buffer
+    is ZERO now (as after GradBuckets.zero_grad() or optimizer.zero_grad()): the first large weight gradient written to a buffer
+    may then be stored instead of accumulated.  Leave it False when gradients are carried over from earlier backward passes."""
+    CACHE.refresh()
+    WGRADS.fresh = bool(fresh_grads)
+
+
 def flush_wgrads():
     """Launch any weight-gradient GEMMs still queued (called automatically at the end of every backward pass)."""
     WGRADS.flush()
@@ -359,8 +395,9 @@ def _tn_notify(*params):
 
 def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor], notify=()):
     """gw += dy^T x, gb += column sums of dy: deferred to a grouped launch when the operands allow it."""
+    first = WGRADS.touch(gw)
     if WGRADS.enabled and not K.EXACT and WGRADS.eligible(dy, x, gw):
-        WGRADS.add(dy, x, gw, gb, notify)
+        WGRADS.add(dy, x, gw, gb, notify, first)
         return
     if WGRADS.enabled and not K.EXACT and WGRADS.eligible_small(dy, x, gw):
         WGRADS.add_small(dy, x, gw, gb, notify)
@@ -475,7 +512,12 @@ class LinearFn(torch.autograd.Function):
         N = (rows[1] - rows[0]) if rows is not None else weight.shape[0]
         if residual is not None:
             r2 = residual.reshape(-1, N)
-            out = _fwd_gemm(x2, weight, bias, rows, epilogue=K.EPI_RESIDUAL, aux=r2.contiguous(), out_dtype=F32)
+            # x W^T + b + residual is an fp32 stream by default; a caller whose sum only feeds further GEMMs may ask for bf16
+            # (the 256-tile kernel's residual epilogue then rounds once on the way out: no fp32 round trip, no cast kernel)
+            Md, Kd2 = x2.shape
+            res16 = (out_dtype == BF16 and not K.EXACT and Md >= _BIG_M and N % 256 == 0 and Kd2 % 64 == 0 and Kd2 >= 128
+                     and -(-Md // 256) * (N // 256) >= 160)
+            out = _fwd_gemm(x2, weight, bias, rows, epilogue=K.EPI_RESIDUAL, aux=r2.contiguous(), out_dtype=BF16 if res16 else F32)
         else:
             out = _fwd_gemm(x2, weight, bias, rows, out_dtype=out_dtype)
         ctx.save_for_backward(x2, weight, bias)
@@ -496,8 +538,11 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, (dy if ctx.has_res else None), None, None
 
 
-def linear(x, weight, bias=None, *, residual=None, rows=None, out_dtype=BF16):
-    """y = x W[rows]^T + b[rows] (+ residual, fp32).  weight may be a conv 1x1 kernel (N, K, 1, 1)."""
+def linear(x, weight, bias=None, *, residual=None, rows=None, out_dtype=None):
+    """y = x W[rows]^T + b[rows] (+ residual).  weight may be a conv 1x1 kernel (N, K, 1, 1).  out_dtype: bf16 by default; with a
+    residual the result is fp32 unless bf16 is asked for explicitly (and the shape takes the 256-tile kernel)."""
+    if out_dtype is None:
+        out_dtype = F32 if residual is not None else BF16
     return LinearFn.apply(x, weight, bias, residual, rows, out_dtype)
 
 
