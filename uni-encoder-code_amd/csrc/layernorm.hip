@@ -9,6 +9,7 @@
 // HBM-bound: a row is read once (16-byte loads, kept in registers), statistics by wave shuffles,
 // output written once.  Algorithmic bytes per row: C * (in + [res] + out [+ h_out]) element sizes.
 #include "common.h"
+#include <stdlib.h>
 
 struct LnFwd {
     const void* x; int x_f32;
@@ -315,7 +316,8 @@ static int ln_bwd_launch(LnBwd& p, float* part_ws, hipStream_t stream) {
     const long M = p.M; const int C = p.C;
     float* dgamma = p.dgamma; float* dbeta = p.dbeta;
     long blocks = (M + 3) / 4;
-    const long cap = (part_ws != nullptr && dgamma != nullptr) ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
+    long cap = (part_ws != nullptr && dgamma != nullptr) ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
+    { const char* e = getenv("UENC_LN_BWD_BLOCKS"); if (e && atoi(e) >= 64 && atoi(e) <= 2048) cap = atoi(e); }     // tuning knob
     if (blocks > cap) blocks = cap;
     // few rows (the decoder's 300-token LayerNorms): the handful of block partials goes straight to dgamma / dbeta by atomics,
     // a second launch would cost more than it saves
