@@ -383,3 +383,44 @@ def test_checkpoint_round_trip_identical_outputs(U, tmp_path):
     r = (rel(oe["pred_logits"], oref["pred_logits"]), rel(oe["pred_masks"], oref["pred_masks"]))
     record_parity("checkpoint/round_trip_vs_oracle_exact", pred_logits=r[0], pred_masks=r[1])
     assert r[0] < 1e-3 and r[1] < 1e-3, r
+
+
+def test_inference_on_dataset_end_to_end(U, tmp_path):
+    """SURVEY.md §8f rank 4 on the HIP path: image files -> DatasetMapper (test-time resize) -> build_detection_test_loader ->
+    inference_on_dataset -> OneFormer.forward -> SemSegEvaluator; outputs come back at each image's ORIGINAL resolution and equal a
+    direct model call on the mapped input."""
+    from PIL import Image
+    from test_exact_gpu import _small_model
+    from uenc.data import DatasetMapper, ResizeShortestEdge, build_detection_test_loader
+    from uenc.evaluation import SemSegEvaluator, inference_on_dataset
+    g = np.random.default_rng(1)
+    dicts = []
+    for i, (h, w) in enumerate([(96, 160), (80, 128), (96, 160), (64, 96), (96, 128), (72, 144), (96, 160)]):
+        arr = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        fn = str(tmp_path / f"i{i}.png")
+        Image.fromarray(arr).save(fn)
+        dicts.append({"file_name": fn, "height": h, "width": w, "image_id": i, "type": "segmentation",
+                      "sem_seg_gt": (arr[:, :, 1] % 19).astype(np.int64)})
+    model = _small_model()
+    mapper = DatasetMapper(is_train=False, seg_augmentations=[ResizeShortestEdge(64, 128)], image_format="RGB", task="semantic")
+    loader = build_detection_test_loader(dicts, mapper=mapper)
+    seen = []
+
+    class Spy(SemSegEvaluator):
+        def process(self, inputs, outputs):
+            seen.append((inputs[0]["image_id"], tuple(outputs[0]["sem_seg"].shape), tuple(inputs[0]["left_image"].shape)))
+            super().process(inputs, outputs)
+    stats = {}
+    res = inference_on_dataset(model, loader, [Spy(19)], stats=stats)
+    assert [s[0] for s in seen] == list(range(7))
+    for (i, shp, in_shp), d in zip(seen, dicts):
+        assert shp == (19, d["height"], d["width"])                       # original resolution
+        assert min(in_shp[1:]) <= 64 and max(in_shp[1:]) <= 128           # the model saw the resized image
+    assert 0.0 <= res["sem_seg"]["mIoU"] <= 100.0 and stats["compute_s_per_iter"] > 0
+    with torch.no_grad():
+        direct = model([mapper(dicts[3])])[0]["sem_seg"]
+    model.eval()
+    with torch.no_grad():
+        again = model([mapper(dicts[3])])[0]["sem_seg"]
+    assert torch.equal(direct, again)
+    record_parity("pipeline/inference_on_dataset", mIoU_random_weights=res["sem_seg"]["mIoU"], compute_s_per_iter=stats["compute_s_per_iter"])

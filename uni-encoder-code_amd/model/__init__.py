@@ -10,5 +10,6 @@ from uenc.config import *  # noqa: F401,F403
 from uenc.config import __all__ as _cfg_all
 from uenc import modeling  # noqa: F401  (registers backbone / heads / decoder)
 from uenc.oneformer_model import OneFormer  # noqa: F401
+from uenc.evaluation import InstanceSegEvaluator  # noqa: F401  (train_net.py:55-56 imports it from `model`)
 
-__all__ = list(_cfg_all) + ["OneFormer", "modeling"]
+__all__ = list(_cfg_all) + ["OneFormer", "modeling", "InstanceSegEvaluator"]
