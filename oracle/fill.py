@@ -42,7 +42,11 @@ def tensor_for(name: str, shape) -> torch.Tensor:
             std = 1.5 * fan_in ** -0.5  # sharper attention logits
         out = n * std
     else:
-        if leaf == "weight":  # LayerNorm / GroupNorm scale
+        if leaf == "running_var":  # BatchNorm running variance: positive, O(1)
+            out = 0.6 + 0.4 * np.abs(n)
+        elif leaf == "num_batches_tracked":
+            return torch.zeros(shape, dtype=torch.int64)
+        elif leaf == "weight":  # LayerNorm / GroupNorm / BatchNorm scale
             out = 1.0 + 0.1 * n
         elif "sampling_offsets" in name:
             out = 2.0 * n  # a few pixels of spread, like the reference's grid init
@@ -53,12 +57,14 @@ def tensor_for(name: str, shape) -> torch.Tensor:
 
 @torch.no_grad()
 def fill_module(module: torch.nn.Module, prefix: str = "") -> None:
-    """Overwrite every floating-point parameter of `module` in place.
-
-    Buffers (e.g. `relative_position_index`) keep their constructed values.
+    """Overwrite every floating-point parameter of `module` in place, and the running statistics of its BatchNorm layers (the
+    sequence-branch decoders run them in eval mode).  Other buffers (e.g. `relative_position_index`) keep their constructed values.
     """
     for name, p in module.named_parameters():
         p.copy_(tensor_for(prefix + name, p.shape))
+    for name, b in module.named_buffers():
+        if name.endswith(("running_mean", "running_var")):
+            b.copy_(tensor_for(prefix + name, b.shape))
 
 
 def state_dict_for(shapes: dict, prefix: str = "") -> dict:

@@ -229,3 +229,34 @@ def load_meta_arch():
     m = _load("model.oneformer_model", "oneformer_model.py")
     ns.OneFormer = m.OneFormer
     return ns
+
+
+def load_sequence():
+    """The reference's "sequence"-branch modules (pose_decoder/resnet_like_pose_decoder.py, motion_decoder/dynamo_motion_decoder_mod.py,
+    pixel_decoder/transdssl.py) and `transformation_from_parameters` of monodepth_loss.py.  The first two import nothing but torch;
+    transdssl.py needs the registry / ShapeSpec stand-ins already installed; monodepth_loss.py imports cv2 (absent) and a
+    distributed helper at module level that the pose functions never touch: both are satisfied by empty name holders."""
+    assert available(), "reference tree not present"
+    _install_stubs()
+    base = os.path.join(REF_ROOT, "model")
+    for name, sub in [("model.modeling.motion_decoder", "modeling/motion_decoder"), ("model.modeling.pose_decoder", "modeling/pose_decoder"),
+                      ("model.utils", "utils")]:
+        if name not in sys.modules or not getattr(sys.modules[name], "__path__", None):
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(base, sub)]
+            sys.modules[name] = m
+    for name in ("model.modeling.motion_decoder.dynamo_motion_decoder_mod", "model.modeling.pose_decoder.resnet_like_pose_decoder",
+                 "model.modeling.monodepth_loss"):
+        m = sys.modules.get(name)
+        if m is not None and getattr(m, "__file__", None) is None:      # name holders left by load_meta_arch()
+            del sys.modules[name]
+    if "cv2" not in sys.modules:
+        _mod("cv2")
+    _mod("model.utils.misc", is_dist_avail_and_initialized=lambda: False)
+    ns = types.SimpleNamespace()
+    ns.pose = _load("model.modeling.pose_decoder.resnet_like_pose_decoder", "modeling/pose_decoder/resnet_like_pose_decoder.py")
+    ns.motion = _load("model.modeling.motion_decoder.dynamo_motion_decoder_mod", "modeling/motion_decoder/dynamo_motion_decoder_mod.py")
+    ns.transdssl = _load("model.modeling.pixel_decoder.transdssl", "modeling/pixel_decoder/transdssl.py")
+    ns.geometry = _load("model.modeling.monodepth_loss", "modeling/monodepth_loss.py")
+    ns.ShapeSpec = _ShapeSpec
+    return ns

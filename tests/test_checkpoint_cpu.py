@@ -57,7 +57,10 @@ def test_wrapper_round_trip_and_oracle_state_dict(tmp_path):
     _same(dict(m2.state_dict()), sd)
     # the oracle consumes the same file as its state dict (names + shapes are the reference's)
     osd = read_checkpoint(path)["model"]
+    from oracle import sequence_ref as SQ
     want = T.model_param_shapes(T.ModelCfg(swin=T.SwinCfg(64, (2, 2, 2, 2), (2, 4, 8, 16), 7)))
+    # + the sequence branch's decoders (always built, reference oneformer_model.py:143-145); this config names no TransDSSL depth decoder
+    want.update({k: v for k, v in SQ.sequence_param_shapes().items() if not k.startswith("sem_seg_head.depth_decoder.")})
     assert {k: tuple(v.shape) for k, v in osd.items() if "relative_position_index" not in k} == {k: tuple(s) for k, s in want.items()}
     img = torch.randint(0, 256, (3, 32, 64), generator=torch.Generator().manual_seed(0)).float()
     with torch.no_grad():

@@ -56,7 +56,9 @@ def test_reference_yaml_chain_builds_the_model():
     cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
     m = build_model(cfg)
     mine = {k: tuple(v.shape) for k, v in m.state_dict().items() if "relative_position_index" not in k}
+    from oracle import sequence_ref as SQ
     want = T.model_param_shapes(T.ModelCfg(swin=T.SWIN_T))
+    want.update(SQ.sequence_param_shapes())   # pose / motion / depth decoders: part of the reference's state dict (oneformer_model.py:143-145)
     assert mine == {k: tuple(s) for k, s in want.items()}      # state-dict names + shapes of the reference
     assert m.backbone.size_divisibility == 32
     assert {k: (v.channels, v.stride) for k, v in m.backbone.output_shape().items()} == {

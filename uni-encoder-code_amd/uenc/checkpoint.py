@@ -78,7 +78,7 @@ def _to_tensor_dict(sd) -> "collections.OrderedDict[str, torch.Tensor]":
     out = collections.OrderedDict()
     for k, v in sd.items():
         if isinstance(v, np.ndarray):
-            v = torch.from_numpy(np.ascontiguousarray(v))
+            v = torch.from_numpy(v if v.flags.c_contiguous else np.ascontiguousarray(v))   # (ascontiguousarray would turn a 0-d array into (1,))
         elif isinstance(v, torch.nn.Parameter):
             v = v.data
         if not torch.is_tensor(v):

@@ -269,6 +269,8 @@ def postproc_panoptic_label(mask_logits: torch.Tensor, ids: torch.Tensor, segid:
 def im2col3x3_s2(x16: torch.Tensor) -> torch.Tensor:
     """x (B, H, W, C) bf16 channels-last -> patch matrix (B * ceil(H/2) * ceil(W/2), 9C) bf16 of the 3x3 stride-2 pad-1 convolution."""
     B, H, W, C = x16.shape
+    if EXACT and x16.dtype == torch.float32:     # pure data movement: the fp32 map gathered as a bf16 map with twice the channels
+        return im2col3x3_s2(x16.contiguous().view(torch.bfloat16)).view(torch.float32)
     assert x16.dtype == torch.bfloat16 and x16.is_contiguous() and C % 8 == 0
     col = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), 9 * C), dtype=torch.bfloat16, device=x16.device)
     check(lib.uenc_im2col3x3_s2(x16.data_ptr(), col.data_ptr(), B, H, W, C, stream_ptr()), "im2col3x3_s2")

@@ -2,8 +2,9 @@
 
 Same registry name, `from_config` keys and `forward(seg_features, depth_features, tasks, mask=None)
 -> (predictions_seg, predictions_depth)` contract.  The depth decoder (`TransDSSL`, sequence branch)
-is outside the hot path: it is built only if a class of that name has been
-registered by the caller, otherwise `depth_decoder` is None and depth features are rejected loudly.
+ is built, like in the reference (:112), from `MODEL.SEM_SEG_HEAD.DEPTH_DECODER_NAME` whenever a class of
+that name is registered (uenc/modeling/pixel_decoder/transdssl.py registers `TransDSSL`); otherwise `depth_decoder` is None and
+depth features are rejected loudly.
 """
 import logging
 from typing import Dict

@@ -1,4 +1,4 @@
-"""`OneFormer` meta-architecture, segmentation branch — counterpart of reference model/oneformer_model.py.
+"""`OneFormer` meta-architecture — counterpart of reference model/oneformer_model.py.
 
 Registered as `OneFormer` in `META_ARCH_REGISTRY`; `forward(batched_inputs: list[dict]) -> list[dict]`
 takes the reference's input dicts (`"type": "segmentation"`, `"left_image"` (3,H,W) RGB uint8/float,
@@ -6,8 +6,11 @@ takes the reference's input dicts (`"type": "segmentation"`, `"left_image"` (3,H
 `"pred_logits"` / `"pred_masks"` tensors).  `forward_features(batched_inputs)` exposes the hot path
 proper (normalise -> backbone -> head, reference :244-253) for training / benchmarking.
 
-Out of scope here: panoptic / instance post-processing and the `"sequence"`
-(depth / pose / motion) branch; a `"sequence"` input raises NotImplementedError.
+Inference post-processing (semantic / panoptic / instance) runs on the device, fused with the mask upsample where no gradient is
+needed (csrc/postproc.hip).  `"type": "sequence"` inputs (`"left_image"` + `"left_prev_image"`) take the depth / pose / motion branch
+of reference :306-365: two more passes of the accelerated backbone, the ego-pose decoder, the two motion decoders and the TransDSSL
+depth decoder (uenc/modeling/{pose_decoder,motion_decoder,pixel_decoder/transdssl}.py; channel counts hard-wired to Swin-T as in the
+reference), convolutions on the HIP GEMMs (uenc/convnet.py).
 """
 from typing import List, Tuple
 
@@ -17,6 +20,8 @@ from torch.nn import functional as F
 
 from . import ops
 from .d2 import META_ARCH_REGISTRY, Boxes, ImageList, Instances, build_backbone, build_sem_seg_head, configurable
+from .modeling.motion_decoder.dynamo_motion_decoder_mod import MotionDecoderV2
+from .modeling.pose_decoder.resnet_like_pose_decoder import ResNetLike
 from .modeling.transformer_decoder.oneformer_transformer_decoder import MLP
 from .tokenizer import Tokenize
 
@@ -24,12 +29,16 @@ from .tokenizer import Tokenize
 @META_ARCH_REGISTRY.register()
 class OneFormer(nn.Module):
     @configurable
-    def __init__(self, *, backbone, sem_seg_head, task_mlp, num_queries: int, object_mask_threshold: float,
+    def __init__(self, *, backbone, sem_seg_head, task_mlp, pose_decoder=None, motion_decoder=None, motion_mask=None, depth_on: bool = True,
+                 num_queries: int, object_mask_threshold: float,
                  overlap_threshold: float, size_divisibility: int, sem_seg_postprocess_before_inference: bool,
                  pixel_mean: Tuple[float], pixel_std: Tuple[float], semantic_on: bool, panoptic_on: bool, instance_on: bool,
                  test_topk_per_image: int, task_seq_len: int, max_seq_len: int, is_demo: bool, **unused):
         super().__init__()
         self.backbone, self.sem_seg_head, self.task_mlp = backbone, sem_seg_head, task_mlp
+        # the sequence branch's decoders (reference :66-68, built unconditionally at :143-145: they are part of the state dict)
+        self.pose_decoder, self.motion_decoder, self.motion_mask = pose_decoder, motion_decoder, motion_mask
+        self.depth_on = depth_on
         self.num_queries = num_queries
         self.overlap_threshold, self.object_mask_threshold = overlap_threshold, object_mask_threshold
         if size_divisibility < 0:
@@ -55,6 +64,8 @@ class OneFormer(nn.Module):
         t = cfg.MODEL.TEST
         return {
             "backbone": backbone, "sem_seg_head": sem_seg_head, "task_mlp": task_mlp,
+            "pose_decoder": ResNetLike(), "motion_decoder": MotionDecoderV2(num_input_images=2, out_dim=3),
+            "motion_mask": MotionDecoderV2(num_input_images=2, out_dim=1), "depth_on": t.DEPTH_ON,
             "num_queries": cfg.MODEL.ONE_FORMER.NUM_OBJECT_QUERIES,
             "object_mask_threshold": t.OBJECT_MASK_THRESHOLD, "overlap_threshold": t.OVERLAP_THRESHOLD,
             "size_divisibility": cfg.MODEL.ONE_FORMER.SIZE_DIVISIBILITY,
@@ -101,8 +112,41 @@ class OneFormer(nn.Module):
         return K.upsample_bilinear(pred_masks.detach().float(), size)
 
     def forward(self, batched_inputs: List[dict]):
+        results = []
+        if any(e["type"] == "segmentation" for e in batched_inputs):
+            results = self._forward_segmentation(batched_inputs)
         if any(e["type"] == "sequence" for e in batched_inputs):
-            raise NotImplementedError("the 'sequence' (depth / pose / motion) branch is out of the hot-path scope, SURVEY.md §8f")
+            results.append(self._forward_sequence([e for e in batched_inputs if e["type"] == "sequence"]))
+        return results
+
+    @torch.no_grad()
+    def _forward_sequence(self, seq: List[dict]) -> dict:
+        """reference :306-365: depth, ego pose and motion of (previous, current) frame pairs.  One result dict for the whole batch,
+        like the reference (`processed_results.append({})` once, :307)."""
+        from .modeling.geometry import transformation_from_parameters
+        if self.pose_decoder is None or self.sem_seg_head.depth_decoder is None:
+            raise NotImplementedError("this model was built without the sequence-branch decoders")
+        norm = lambda key: ImageList.from_tensors([(x[key].to(self.device) - self.pixel_mean) / self.pixel_std for x in seq], self.size_divisibility)
+        cur, prev = norm("left_image"), norm("left_prev_image")
+        f_cur = self.backbone(cur.tensor)
+        f_prev = self.backbone(prev.tensor)
+        f_motion = {k: torch.cat([f_prev[k].float(), v.float()], dim=1) for k, v in f_cur.items()}
+        axisangle, translation = self.pose_decoder(f_motion)
+        axisangle, translation = axisangle[:, 0], translation[:, 0]
+        cam = transformation_from_parameters(axisangle, translation, invert=True)
+        motion = {"motion_input": {"full_res_input": torch.cat([prev.tensor, cur.tensor], dim=1), **f_motion}}
+        ego = torch.cat((translation, axisangle), -1).permute(0, 2, 1).unsqueeze(3)
+        flow = self.motion_decoder(motion, ego)
+        mask = self.motion_mask(motion, ego)
+        dummy_tasks = torch.zeros((cur.tensor.shape[0], self.task_mlp.layers[1].out_features), device=self.device)
+        _, depth = self.sem_seg_head(None, f_cur, dummy_tasks)
+        out = {}
+        if self.depth_on:
+            out = {"disp_results": depth[("disp", 0)], "motion_mask": mask[("motion_mask", 0)], "complete_flow": flow[("complete_flow", 0)],
+                   "cam_T_cam": cam}
+        return out
+
+    def _forward_segmentation(self, batched_inputs: List[dict]):
         outputs, images = self.forward_features(batched_inputs)
         mask_cls_results = outputs["pred_logits"]
         padded = tuple(images.tensor.shape[-2:])

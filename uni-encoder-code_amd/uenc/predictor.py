@@ -2,8 +2,11 @@
 
 `DefaultPredictor(cfg)(image_rgb_uint8_hwc, task)` builds the model through the registries, resizes the
 shortest edge to `INPUT.SEG_MIN_SIZE_TEST` (capped by `SEG_MAX_SIZE_TEST`) like the reference's
-`ResizeShortestEdge` (:59-61, 157-158) and runs one forward.  The reference's second, 192x512
-"sequence" call (:96-97) belongs to the out-of-scope depth branch.
+`ResizeShortestEdge` (:59-61, 157-158) and runs one forward.  With a `previous_frame` it also makes the
+reference's second call (:84-97): both frames resized to 192 x 512, `"type": "sequence"`, and returns that
+branch's tensors (`disp_results` -> `depth` through `disp_to_depth`, `motion_mask`, `complete_flow`, `cam_T_cam`)
+next to the segmentation outputs.  The reference's colour-mapping of those tensors into PIL images (:98-155, with a
+camera file read from a hard-coded path) is visualisation and stays out.
 """
 import torch
 import torch.nn.functional as F
@@ -32,10 +35,29 @@ class DefaultPredictor:
         return F.interpolate(img[None], size=(nh, nw), mode="bilinear", align_corners=False)[0]
 
     @torch.no_grad()
-    def __call__(self, original_image, task="panoptic"):
-        """original_image: (H, W, 3) uint8 RGB tensor / array."""
+    def __call__(self, original_image, task="panoptic", previous_frame=None):
+        """original_image (and previous_frame): (H, W, 3) uint8 RGB tensor / array."""
         img = torch.as_tensor(original_image)
         height, width = img.shape[:2]
-        img = self._resize(img.permute(2, 0, 1).float())
-        inputs = {"left_image": img, "height": height, "width": width, "task": f"The task is {task}", "type": "segmentation"}
-        return self.model([inputs])[0]
+        chw = img.permute(2, 0, 1).float()
+        inputs = {"left_image": self._resize(chw), "height": height, "width": width, "task": f"The task is {task}", "type": "segmentation"}
+        out = self.model([inputs])[0]
+        if previous_frame is not None:
+            small = lambda t: F.interpolate(t[None], size=SEQUENCE_SIZE, mode="bilinear", align_corners=False)[0]
+            prev = torch.as_tensor(previous_frame).permute(2, 0, 1).float()
+            seq = self.model([{"left_image": small(chw), "left_prev_image": small(prev), "height": height, "width": width,
+                               "task": f"The task is {task}", "type": "sequence"}])[0]
+            if "disp_results" in seq:
+                seq["scaled_disp"], seq["depth"] = disp_to_depth(seq["disp_results"])
+            out = {**out, **seq}
+        return out
+
+
+SEQUENCE_SIZE = (192, 512)            # demo/defaults.py:84-86
+
+
+def disp_to_depth(disp, min_depth=0.1, max_depth=100.0):
+    """sigmoid disparity -> (scaled disparity, depth), reference model/modeling/monodepth_loss.py:103-112."""
+    min_disp, max_disp = 1 / max_depth, 1 / min_depth
+    scaled = min_disp + (max_disp - min_disp) * disp
+    return scaled, 1 / scaled
