@@ -103,6 +103,22 @@ def test_pixel_decoder_golden(U):
         assert rel(ms[i], g[f"ms{i}"]) < 2e-2, i
 
 
+def test_pixel_decoder_unfused_side_paths(U, monkeypatch):
+    """The branches a GroupNorm shape outside the channels-last kernels' domain takes (ATen group norm on the 1x1 projections,
+    the unfused FPN merge: msdeformattn.py `_conv1x1_gn` / the `not fused` arm) against the same reference fixture."""
+    import uenc.modeling.pixel_decoder.msdeformattn as M
+    g = load_golden("pixel_decoder")
+    ch = {k: g[k].shape[1] for k in ("res2", "res3", "res4", "res5")}
+    pd, _ = _head_modules(U, ch)
+    monkeypatch.setattr(M, "_gn_tokens_ok", lambda gn: False)
+    with torch.no_grad():
+        mf, _, ms = pd.forward_features({k: g[k].cuda() for k in ch})
+    record_parity("bf16/pixel_decoder_unfused_paths", mask_features=rel(mf, g["mask_features"]), **{f"ms{i}": rel(ms[i], g[f"ms{i}"]) for i in range(3)})
+    assert rel(mf, g["mask_features"]) < 2e-2
+    for i in range(3):
+        assert rel(ms[i], g[f"ms{i}"]) < 2e-2, i
+
+
 def test_transformer_decoder_golden(U):
     """Two checks.  (a) With the reference's boolean attention masks forced (fixture), every prediction is within
     bf16 tolerance of the reference: the arithmetic is right.  (b) Free-running, the masks are thresholded

@@ -17,25 +17,7 @@
 // per key over its inverse neighbourhood (dk, dv).  HBM traffic is q, k, v, out once each (the window re-reads hit L1 / L2):
 // algorithmic bytes = 4 * B*H*W*C * 2 forward, memory-side bound.
 #include "common.h"
-
-struct Na2d {
-    const bf16* qkv; const float* rpb; bf16* out; float* lse;
-    const bf16* dout; bf16* dqkv; float* drpb; float* delta;
-    int B, H, W, nH, d;
-    float scale;
-    int hh_max, hw_max;      // bwd_kv tiled: LDS halo extents (class positions) for this launch
-};
-
-struct AxisWin { int start, r, pb0; };       // first class position of the window, residue, bias index of slot 0
-
-__device__ __forceinline__ AxisWin axis_win(int t, int len, int d, int K) {
-    AxisWin a;
-    a.r = t % d;
-    const int p = t / d, L = (len - a.r + d - 1) / d;
-    a.start = min(max(p - K / 2, 0), L - K);
-    a.pb0 = a.start - p + K - 1;
-    return a;
-}
+#include "na2d.h"
 
 // Cross-lane sums on DPP (VALU data-parallel primitives): __shfl_xor compiles to ds_bpermute, which goes through the LDS
 // crossbar and competes with the halo reads of the tiled kernels.
@@ -545,8 +527,9 @@ extern "C" int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float
     p.B = B; p.H = H; p.W = W; p.nH = nH; p.d = dilation; p.scale = scale;
     const int rc = na2d_check(p, K);
     if (rc != UENC_OK) return rc;
-    const char* ev = getenv("UENC_NA2D_VARIANT");
-    if (ev && (atoi(ev) & 1)) {                                // A/B: the direct (L1-gather) kernel
+    const char* ev = getenv("UENC_NA2D_VARIANT");              // A/B: 1 = the direct (L1-gather) kernels, 2 = the LDS-tiled VALU kernels
+    if (K <= 7 && !(ev && (atoi(ev) & 3))) return na2d_mfma_fwd(p, K, stream);          // matrix cores (na2d_mfma.hip)
+    if (ev && (atoi(ev) & 1)) {
         const dim3 grid((W + 63) / 64, H, B * nH);
         NA2D_DISPATCH(na2d_fwd_kernel);
     } else {
@@ -571,6 +554,7 @@ extern "C" int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out,
     const int rc = na2d_check(p, K);
     if (rc != UENC_OK) return rc;
     const char* ev = getenv("UENC_NA2D_VARIANT");
+    if (K <= 7 && !(ev && (atoi(ev) & 3))) return na2d_mfma_bwd(p, K, stream);           // matrix cores (na2d_mfma.hip)
     const bool direct = ev && (atoi(ev) & 1);                 // A/B: the direct (L1-gather) kernels
     const int Lx = (W + dilation - 1) / dilation, Ly = (H + dilation - 1) / dilation;
     const dim3 tgrid(((Lx + NA_TW - 1) / NA_TW) * dilation, ((Ly + NA_TH - 1) / NA_TH) * dilation, B * nH);

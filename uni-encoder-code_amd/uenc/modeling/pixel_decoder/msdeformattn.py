@@ -6,9 +6,11 @@ Same class names, constructor arguments and parameter names (`input_proj.{i}.{0,
 encoder_out[0], multi_scale_features)` contract, registered as `MSDeformAttnPixelDecoder`.
 
 Tokens stay channels-last `(B, sum(HW), 256)` fp32 through the encoder; every Linear / 1x1 conv is a
-bf16 MFMA GEMM with fused bias / ReLU / residual epilogues, LayerNorm and the deformable sampling
-core are HIP kernels.  Still on ATen (plumbing, listed in DESIGN.md "not yet HIP"): GroupNorm, the
-single 3x3 FPN conv, bilinear resize, the 12-way softmax and sampling-location arithmetic.
+bf16 MFMA GEMM with fused bias / ReLU / residual epilogues; LayerNorm, GroupNorm (channels-last, with the
+FPN top-down merge and ReLU folded in), the 3x3 FPN conv (patch gather + GEMM), the 12-way softmax with the
+sampling-location arithmetic (`msda_prep`) and the deformable sampling core are HIP kernels.  ATen remains
+only for a GroupNorm shape outside the kernels' domain and a non-GroupNorm `norm` (no reference config has
+either; tests/test_model_gpu.py::test_pixel_decoder_unfused_side_paths drives those arms).
 """
 from typing import Callable, Dict, List, Optional, Union
 
