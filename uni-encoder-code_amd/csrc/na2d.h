@@ -8,6 +8,7 @@ struct Na2d {
     int B, H, W, nH, d;
     float scale;
     int hh_max, hw_max;      // bwd_kv tiled: LDS halo extents (class positions) for this launch
+    int tiles_x, tiles_y, nt; float inv_tiles_x;     // MFMA kernels: tiles per residue class, tiles per workgroup
 };
 
 struct AxisWin { int start, r, pb0; };       // first class position of the window, residue, bias index of slot 0
@@ -24,3 +25,4 @@ __device__ __forceinline__ AxisWin axis_win(int t, int len, int d, int K) {
 // na2d_mfma.hip
 int na2d_mfma_fwd(const Na2d& p, int K, hipStream_t stream);
 int na2d_mfma_bwd(Na2d& p, int K, hipStream_t stream);
+bool na2d_mfma_supported(int H, int W, int nH, int K, int dilation);

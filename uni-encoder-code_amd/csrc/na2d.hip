@@ -528,7 +528,7 @@ extern "C" int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float
     const int rc = na2d_check(p, K);
     if (rc != UENC_OK) return rc;
     const char* ev = getenv("UENC_NA2D_VARIANT");              // A/B: 1 = the direct (L1-gather) kernels, 2 = the LDS-tiled VALU kernels
-    if (K <= 7 && !(ev && (atoi(ev) & 3))) return na2d_mfma_fwd(p, K, stream);          // matrix cores (na2d_mfma.hip)
+    if (na2d_mfma_supported(H, W, nH, K, dilation) && !(ev && (atoi(ev) & 3))) return na2d_mfma_fwd(p, K, stream);          // matrix cores (na2d_mfma.hip)
     if (ev && (atoi(ev) & 1)) {
         const dim3 grid((W + 63) / 64, H, B * nH);
         NA2D_DISPATCH(na2d_fwd_kernel);
@@ -554,7 +554,7 @@ extern "C" int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out,
     const int rc = na2d_check(p, K);
     if (rc != UENC_OK) return rc;
     const char* ev = getenv("UENC_NA2D_VARIANT");
-    if (K <= 7 && !(ev && (atoi(ev) & 3))) return na2d_mfma_bwd(p, K, stream);           // matrix cores (na2d_mfma.hip)
+    if (na2d_mfma_supported(H, W, nH, K, dilation) && !(ev && (atoi(ev) & 3))) return na2d_mfma_bwd(p, K, stream);           // matrix cores (na2d_mfma.hip)
     const bool direct = ev && (atoi(ev) & 1);                 // A/B: the direct (L1-gather) kernels
     const int Lx = (W + dilation - 1) / dilation, Ly = (H + dilation - 1) / dilation;
     const dim3 tgrid(((Lx + NA_TW - 1) / NA_TW) * dilation, ((Ly + NA_TH - 1) / NA_TH) * dilation, B * nH);

@@ -10,6 +10,12 @@
 // the PV product as its B operand (k-slots in accumulator order, V^T through the transposing LDS read) -- P never touches LDS.
 // 2 (K + 1) MFMAs per 16 queries at 49 / 128 useful scores (K = 7), against 49 x 26 VALU instructions per query before.
 //
+// Schedule.  A workgroup walks `nt` consecutive tiles of one residue class: the halo of tile t + 1 is loaded into registers before the
+// arithmetic of tile t and written to LDS after it, so the L2 -> LDS staging (half of every 128-byte line belongs to the neighbouring
+// head: the staging runs at the L2's line rate) overlaps the VALU-bound softmax instead of alternating with it, the bias table is
+// built once per workgroup, and the grid shrinks from one workgroup per tile (the dispatcher alone took 25 us at 12 288 tiles) to
+// a few per CU.  All index arithmetic is 32-bit (the launcher checks H * W * 3C < 2^31; integer multiplies are quarter rate).
+//
 // Bias: rpb[key - query + K - 1] per axis.  The 4 scores a lane holds per block are 4 consecutive bias columns: the table sits in LDS
 // in 4 copies shifted by 0..3 floats, so that every lane reads its 4 values with one aligned ds_read_b128.
 //
@@ -33,31 +39,105 @@ struct NmGeom {
     static constexpr int HH = NM_TH + K;                                 // halo rows + one spare (a wave's last key block may be all padding)
     static constexpr int HWP = ((NM_TW + K - 1 + 7) / 8) * 8;            // halo row stride in positions
     static constexpr int NPOS = HH * HWP + 8;                            // + tail: a 16-position block starts at column <= 15 of a 24-wide row
-    static constexpr int TAB = 4 * RB * 32;                              // bias table: 4 shifted copies of [RB][32]
+    static constexpr int NIT = (NPOS + 127) / 128;                       // staging passes: 128 positions x 4 chunks per pass
+    static constexpr int TAB = RB * 128;                                 // bias table: [RB][4 shifted copies][32]
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a + 0.5f) * inv_b); }      // exact for the small counts used here
 
-// stage the halo [hsy, hsy + hh) x [hsx, hsx + hw) of one head slice (element offset `off` inside a pixel's `stride` elements) as an
-// LDS image of NPOS positions; positions outside the halo are zero (they are read as masked operands: must be finite)
-template <int NPOS, int HWP>
-__device__ __forceinline__ void nm_stage(unsigned char* img, const bf16* src, long stride, const Na2d& p, int b, int ry, int rx,
-                                         int hsy, int hsx, int hh, int hw) {
-    for (int i = threadIdx.x; i < NPOS * 4; i += 512) {
-        const int c = i & 3, pos = i >> 2;
-        const int yy = pos / HWP, xx = pos - yy * HWP;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (yy < hh && xx < hw)
-            v = *(const u32x4*)(src + (((long)b * p.H + (hsy + yy) * p.d + ry) * p.W + (hsx + xx) * p.d + rx) * stride + c * 8);
-        *(u32x4*)(img + rm_off(pos, c)) = v;
-    }
+// workgroup -> (image, head, residue class, tile range); grid (chunks per class, d * d, B * nH)
+struct NmWork { int b, h, ry, rx, Ly, Lx, t0, t1; };
+__device__ __forceinline__ NmWork nm_work(const Na2d& p) {
+    NmWork w;
+    w.h = blockIdx.z % p.nH; w.b = blockIdx.z / p.nH;
+    w.ry = blockIdx.y / p.d; w.rx = blockIdx.y - w.ry * p.d;
+    w.Ly = (p.H - w.ry + p.d - 1) / p.d; w.Lx = (p.W - w.rx + p.d - 1) / p.d;      // this class's extent
+    w.t0 = blockIdx.x * p.nt; w.t1 = min(w.t0 + p.nt, p.tiles_y * p.tiles_x);
+    return w;
+}
+
+// one tile of one residue class (all fields workgroup-uniform)
+struct NmTile {
+    int ry, rx, py0, px0, Ly, Lx;
+    int hsy, hsx, hh, hw;           // halo origin (class positions) and extent
+    bool ok;                        // false: the tile lies outside this (ragged) class -- nothing to do
+};
+
+// forward / per-query backward: halo = union of the windows of the tile's queries
+template <int K>
+__device__ __forceinline__ NmTile nm_tile_q(const Na2d& p, const NmWork& w, int t) {
+    constexpr int NS = K / 2;
+    NmTile g;
+    g.ry = w.ry; g.rx = w.rx; g.Ly = w.Ly; g.Lx = w.Lx;
+    const int tyi = fdiv(t, p.inv_tiles_x), txi = t - tyi * p.tiles_x;
+    g.py0 = tyi * NM_TH; g.px0 = txi * NM_TW;
+    g.ok = g.py0 < g.Ly && g.px0 < g.Lx;
+    g.hsy = clampi(g.py0 - NS, 0, g.Ly - K); g.hsx = clampi(g.px0 - NS, 0, g.Lx - K);
+    g.hh = clampi(min(g.py0 + NM_TH, g.Ly) - 1 - NS, 0, g.Ly - K) + K - g.hsy;
+    g.hw = clampi(min(g.px0 + NM_TW, g.Lx) - 1 - NS, 0, g.Lx - K) + K - g.hsx;
+    return g;
 }
 
 template <int K>
+__device__ __forceinline__ int inv_start(int pos) { return pos < K ? 0 : pos - K / 2; }
+template <int K>
+__device__ __forceinline__ int inv_end(int pos, int L) { return pos >= L - K ? L : pos + K / 2 + 1; }
+
+// per-key backward: halo = union of the inverse neighbourhoods of the tile's keys
+template <int K>
+__device__ __forceinline__ NmTile nm_tile_kv(const Na2d& p, const NmWork& w, int t) {
+    NmTile g;
+    g.ry = w.ry; g.rx = w.rx; g.Ly = w.Ly; g.Lx = w.Lx;
+    const int tyi = fdiv(t, p.inv_tiles_x), txi = t - tyi * p.tiles_x;
+    g.py0 = tyi * NM_TH; g.px0 = txi * NM_TW;
+    g.ok = g.py0 < g.Ly && g.px0 < g.Lx;
+    const int pyl = min(g.py0 + NM_TH, g.Ly) - 1, pxl = min(g.px0 + NM_TW, g.Lx) - 1;          // last key of the tile
+    g.hsy = inv_start<K>(g.py0); g.hsx = inv_start<K>(g.px0);
+    g.hh = inv_end<K>(pyl, g.Ly) - g.hsy; g.hw = inv_end<K>(pxl, g.Lx) - g.hsx;
+    return g;
+}
+
+// Halo staging in two halves: `issue` loads the k and v (or q and dout) chunks of the tile's halo positions into registers, `commit`
+// writes them to the LDS images.  Thread -> chunk c = tid & 3 of positions (tid >> 2) + 128 it.  Positions outside the halo are
+// zero (they are read as masked operands: must be finite).
+template <int NPOS, int HWP, int NIT>
+struct NmStage {
+    u32x4 a[NIT], b[NIT];
+    __device__ __forceinline__ void issue(const NmTile& g, const bf16* src, int d01, unsigned rowstride, unsigned colstride) {
+        const int c = threadIdx.x & 3;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pos = (threadIdx.x >> 2) + it * 128;
+            const int yy = pos / HWP, xx = pos - yy * HWP;
+            a[it] = (u32x4){0u, 0u, 0u, 0u}; b[it] = a[it];
+            if (g.ok && yy < g.hh && xx < g.hw) {
+                const bf16* gp = src + ((unsigned)yy * rowstride + (unsigned)xx * colstride + c * 8);
+                a[it] = *(const u32x4*)gp;
+                b[it] = *(const u32x4*)(gp + d01);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(unsigned char* img0, unsigned char* img1) const {
+        const int c = threadIdx.x & 3;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pos = (threadIdx.x >> 2) + it * 128;
+            if ((NPOS % 128) == 0 || pos < NPOS) {
+                const int off = rm_off(pos, c);
+                *(u32x4*)(img0 + off) = a[it];
+                *(u32x4*)(img1 + off) = b[it];
+            }
+        }
+    }
+};
+
+// bias table [RB rows][4 copies][32]: copy e, position i holds bias column i + e - 8 (zero outside [0, RB)), times log2 e
+template <int K>
 __device__ __forceinline__ void nm_bias_table(float* tab, const float* rpb, int h) {
     constexpr int RB = 2 * K - 1;
-    for (int i = threadIdx.x; i < 4 * RB * 32; i += 512) {
-        const int e = i / (RB * 32), rem = i - e * RB * 32, row = rem >> 5, col = (rem & 31) + e - 8;
+    for (int i = threadIdx.x; i < RB * 128; i += 512) {
+        const int row = i >> 7, e = (i >> 5) & 3, col = (i & 31) + e - 8;
         tab[i] = (rpb != nullptr && col >= 0 && col < RB) ? rpb[(h * RB + row) * RB + col] * LOG2E : 0.f;
     }
 }
@@ -65,39 +145,60 @@ __device__ __forceinline__ void nm_bias_table(float* tab, const float* rpb, int 
 // per-lane description of a wave's 2 x 8 query block inside the workgroup's halo
 struct NmQuery {
     bool wave_active, valid;
-    long pix;                 // this lane's query pixel (clamped to a valid one)
-    int r0;                   // image position of key block 0, key column 0
+    unsigned pix;             // this lane's query pixel inside the image b (clamped to a valid one)
     int dy0, dx0;             // this query's window start relative to the wave's key region
-    int by0, j0;              // bias row of key block 0; bias column of key column 4 fg
-    long si;                  // index into (B, nH, H, W) statistics
+    int by0;                  // bias row of key block 0
+    int bcol0;                // bias column of key column 0 for the wave's first query column (lane-uniform part of the drpb bins)
+    int boff;                 // float offset of this lane's 4 bias columns inside a table row (copy + aligned position)
+    unsigned a_rows;          // byte offset of this lane's operand row of key block 0 (frag_rows); block kt: + kt * HWP * 64
+    unsigned a_tr[2];         // byte offsets of the transposing reads of key block 0 for output dims 0..15 / 16..31; block kt likewise
 };
 
 template <int K>
-__device__ __forceinline__ NmQuery nm_query(const Na2d& p, int b, int h, int ry, int rx, int py0, int px0, int Ly, int Lx, int hsy, int hsx) {
+__device__ __forceinline__ NmQuery nm_query(const Na2d& p, const NmTile& g) {
     constexpr int NS = K / 2, HWP = NmGeom<K>::HWP;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
     const int wy = wave >> 1, wx = wave & 1;
     NmQuery q;
-    q.wave_active = (py0 + 2 * wy < Ly) && (px0 + 8 * wx < Lx);
-    const int py_a = min(py0 + 2 * wy, Ly - 1), px_a = min(px0 + 8 * wx, Lx - 1);
-    const int pyr = py0 + 2 * wy + (fr >> 3), pxr = px0 + 8 * wx + (fr & 7);
-    q.valid = pyr < Ly && pxr < Lx;
-    const int py = min(pyr, Ly - 1), px = min(pxr, Lx - 1);
-    const int sy_a = clampi(py_a - NS, 0, Ly - K), sx_a = clampi(px_a - NS, 0, Lx - K);
-    const int sy = clampi(py - NS, 0, Ly - K), sx = clampi(px - NS, 0, Lx - K);
+    q.wave_active = (g.py0 + 2 * wy < g.Ly) && (g.px0 + 8 * wx < g.Lx);
+    const int py_a = min(g.py0 + 2 * wy, g.Ly - 1), px_a = min(g.px0 + 8 * wx, g.Lx - 1);
+    const int pyr = g.py0 + 2 * wy + (fr >> 3), pxr = g.px0 + 8 * wx + (fr & 7);
+    q.valid = pyr < g.Ly && pxr < g.Lx;
+    const int py = min(pyr, g.Ly - 1), px = min(pxr, g.Lx - 1);
+    const int sy_a = clampi(py_a - NS, 0, g.Ly - K), sx_a = clampi(px_a - NS, 0, g.Lx - K);
+    const int sy = clampi(py - NS, 0, g.Ly - K), sx = clampi(px - NS, 0, g.Lx - K);
     q.dy0 = sy - sy_a; q.dx0 = sx - sx_a;
-    q.r0 = (sy_a - hsy) * HWP + (sx_a - hsx);
+    const int r0 = (sy_a - g.hsy) * HWP + (sx_a - g.hsx);          // image position of key block 0, key column 0
     q.by0 = sy_a - py + K - 1;
-    q.j0 = 4 * fg + sx_a - px + K - 1;
-    const int y = py * p.d + ry, x = px * p.d + rx;
-    q.pix = ((long)b * p.H + y) * p.W + x;
-    q.si = (((long)b * p.nH + h) * p.H + y) * p.W + x;
+    q.bcol0 = sx_a - px_a + K - 1;
+    const int j0 = 4 * fg + sx_a - px + K - 1;                     // bias column of key column 4 fg: in [-7, K + 11]
+    q.boff = ((j0 + 8) & 3) * 32 + ((j0 + 8) & ~3);
+    // HWP is a multiple of 8 rows, so the row swizzle ((row >> 1) & 3) is the same in every key block: constant block strides
+    q.a_rows = rm_off(r0 + fr, fg);
+    {
+        const int q4 = fr >> 2, p4 = fr & 3;
+        const int a0 = rm_off(r0 + 4 * fg + q4, p4 >> 1) + ((p4 & 1) << 3);
+        q.a_tr[0] = a0; q.a_tr[1] = a0 ^ 32;
+    }
+    q.pix = (unsigned)(py * p.d + g.ry) * p.W + px * p.d + g.rx;
     return q;
 }
 
-__device__ __forceinline__ f32x4 nm_bias4(const float* tab, int RB, int by, int j0) {
-    const int e = (j0 + 8) & 3, pos = (j0 + 8) - e;
-    return *(const f32x4*)(tab + (e * RB + by) * 32 + pos);
+__device__ __forceinline__ f32x4 nm_bias4(const float* tab, int by, int boff) { return *(const f32x4*)(tab + by * 128 + boff); }
+
+template <int HWP>
+__device__ __forceinline__ bf16x8 nm_rows(const unsigned char* img, unsigned a_rows, int kt) { return *(const bf16x8*)(img + a_rows + kt * HWP * 64); }
+
+// A operand M^T[dim][k] of the products that sum over two key blocks (kt, kt + 1): k-slots 0..3 <- block kt keys 4 fg + 0..3, 4..7 <- block kt + 1
+template <int HWP>
+__device__ __forceinline__ bf16x8 nm_tr(const unsigned char* img, unsigned a_tr, int kt) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + a_tr + kt * HWP * 64));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + a_tr + (kt + 1) * HWP * 64));
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
+    return r;
 }
 
 __device__ __forceinline__ void nm_store4(bf16* dst, const f32x4& v, float mul) {
@@ -108,311 +209,382 @@ __device__ __forceinline__ void nm_store4(bf16* dst, const f32x4& v, float mul) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// forward.  grid (tiles_x * d, tiles_y * d, B * nH), block 512
+// forward
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(512) void na2d_mfma_fwd_kernel(Na2d p) {
     typedef NmGeom<K> G;
-    constexpr int NS = G::NS, RB = G::RB, NKT = G::NKT, HWP = G::HWP;
+    constexpr int RB = G::RB, NKT = G::NKT, HWP = G::HWP;
     __shared__ __attribute__((aligned(16))) unsigned char ks[G::NPOS * 64];
     __shared__ __attribute__((aligned(16))) unsigned char vs[G::NPOS * 64];
     __shared__ __attribute__((aligned(16))) float tab[G::TAB];
-    const int h = blockIdx.z % p.nH, b = blockIdx.z / p.nH;
-    const int ry = blockIdx.y % p.d, rx = blockIdx.x % p.d;
-    const int py0 = (blockIdx.y / p.d) * NM_TH, px0 = (blockIdx.x / p.d) * NM_TW;
-    const int Ly = (p.H - ry + p.d - 1) / p.d, Lx = (p.W - rx + p.d - 1) / p.d;
-    if (py0 >= Ly || px0 >= Lx) return;                    // (uniform: before any barrier)
+    const NmWork w = nm_work(p);
     const int C = p.nH * 32;
-    const int hsy = clampi(py0 - NS, 0, Ly - K), hey = clampi(min(py0 + NM_TH, Ly) - 1 - NS, 0, Ly - K) + K;
-    const int hsx = clampi(px0 - NS, 0, Lx - K), hex = clampi(min(px0 + NM_TW, Lx) - 1 - NS, 0, Lx - K) + K;
-    nm_bias_table<K>(tab, p.rpb, h);
-    nm_stage<G::NPOS, HWP>(ks, p.qkv + C + h * 32, 3L * C, p, b, ry, rx, hsy, hsx, hey - hsy, hex - hsx);
-    nm_stage<G::NPOS, HWP>(vs, p.qkv + 2 * C + h * 32, 3L * C, p, b, ry, rx, hsy, hsx, hey - hsy, hex - hsx);
-    __syncthreads();
-    const NmQuery q = nm_query<K>(p, b, h, ry, rx, py0, px0, Ly, Lx, hsy, hsx);
-    if (!q.wave_active) return;                             // whole waves: EXEC stays full for the transposing reads below
-    const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
-    const bf16x8 qf = *(const bf16x8*)(p.qkv + q.pix * 3 * C + h * 32 + 8 * fg);
+    const unsigned colstride = p.d * 3 * C, rowstride = colstride * p.W;
+    const bf16* qkv_b = p.qkv + (long)w.b * p.H * p.W * 3 * C + w.h * 32;          // this image, this head's q slice
+    bf16* out_b = p.out + (long)w.b * p.H * p.W * C + w.h * 32;
+    float* lse_b = p.lse ? p.lse + ((long)w.b * p.nH + w.h) * p.H * p.W : nullptr;
+    const int lane = threadIdx.x & 63, fg = lane >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const float sc = p.scale * LOG2E;
-    bool colok[4];
+    nm_bias_table<K>(tab, p.rpb, w.h);
+    NmStage<G::NPOS, HWP, G::NIT> st;
+    NmTile g = nm_tile_q<K>(p, w, w.t0);
+    auto issue = [&](const NmTile& t) {
+        st.issue(t, qkv_b + ((unsigned)(t.hsy * p.d + t.ry) * p.W + t.hsx * p.d + t.rx) * (unsigned)(3 * C) + C, C, rowstride, colstride);
+    };
+    issue(g);
+    for (int t = w.t0; t < w.t1; ++t) {
+        __syncthreads();                                   // the previous tile's LDS reads are done
+        st.commit(ks, vs);
+        __syncthreads();
+        // this tile's own global operand first: loads return in order, a wait on q would otherwise also wait for the prefetch behind it
+        const NmQuery q = nm_query<K>(p, g);
+        const bf16x8 qf = *(const bf16x8*)(qkv_b + q.pix * (unsigned)(3 * C) + 8 * fg);
+        NmTile gn = g;
+        if (t + 1 < w.t1) { gn = nm_tile_q<K>(p, w, t + 1); issue(gn); }      // in flight during the arithmetic below
+        if (g.ok && q.wave_active) {                       // whole waves: EXEC stays full for the transposing reads
+            bool colok[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) colok[r] = (unsigned)(4 * fg + r - q.dx0) < (unsigned)K;
-    f32x4 s[NKT];
-    float m = NEG_BIG;
+            for (int r = 0; r < 4; ++r) colok[r] = (unsigned)(4 * fg + r - q.dx0) < (unsigned)K;
+            f32x4 s[NKT];
+            float m = NEG_BIG;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        s[kt] = mfma16(frag_rows(ks, q.r0 + kt * HWP, fr, fg), qf, zero4);
-        const f32x4 bias = nm_bias4(tab, RB, clampi(q.by0 + kt, 0, RB - 1), q.j0);
-        const bool rowok = (unsigned)(kt - q.dy0) < (unsigned)K;
+            for (int kt = 0; kt < NKT; ++kt) {
+                s[kt] = mfma16(nm_rows<HWP>(ks, q.a_rows, kt), qf, zero4);
+                const f32x4 bias = nm_bias4(tab, clampi(q.by0 + kt, 0, RB - 1), q.boff);
+                const bool rowok = (unsigned)(kt - q.dy0) < (unsigned)K;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[kt][r] = (rowok && colok[r]) ? s[kt][r] * sc + bias[r] : NEG_BIG;
-            m = fmaxf(m, s[kt][r]);
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = (rowok && colok[r]) ? s[kt][r] * sc + bias[r] : NEG_BIG;
+                    m = fmaxf(m, s[kt][r]);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = fast_exp2(s[kt][r] - m);
+                    l += s[kt][r];
+                }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            f32x4 o[2] = {zero4, zero4};
+#pragma unroll
+            for (int s2 = 0; s2 < NKT / 2; ++s2) {
+                bf16x8 pb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pb[r] = (bf16)s[2 * s2][r]; pb[4 + r] = (bf16)s[2 * s2 + 1][r]; }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16(nm_tr<HWP>(vs, q.a_tr[dt], 2 * s2), pb, o[dt]);
+            }
+            if (q.valid) {
+                const float inv = 1.0f / l;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) nm_store4(out_b + q.pix * (unsigned)C + dt * 16 + 4 * fg, o[dt], inv);
+                if (fg == 0 && lse_b) lse_b[q.pix] = (m + __log2f(l)) * LN2;
+            }
         }
+        g = gn;
     }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[kt][r] = fast_exp2(s[kt][r] - m);
-            l += s[kt][r];
-        }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    f32x4 o[2] = {zero4, zero4};
-#pragma unroll
-    for (int s2 = 0; s2 < NKT / 2; ++s2) {
-        bf16x8 pb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { pb[r] = (bf16)s[2 * s2][r]; pb[4 + r] = (bf16)s[2 * s2 + 1][r]; }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-            o[dt] = mfma16(frag_tr(vs, q.r0 + 2 * s2 * HWP, q.r0 + (2 * s2 + 1) * HWP, dt * 16, lane), pb, o[dt]);
-    }
-    if (!q.valid) return;
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) nm_store4(p.out + q.pix * C + h * 32 + dt * 16 + 4 * fg, o[dt], inv);
-    if (fg == 0 && p.lse) p.lse[q.si] = (m + __log2f(l)) * LN2;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward per query: dq, drpb, delta.  Same grid.
+// backward per query: dq, drpb, delta
 // ---------------------------------------------------------------------------------------------------------------------
+// drpb.  dS of a key block sits in the lanes as [query (lane & 15)][key column 4 fg + r]; its bias bin is (kt - query row + by_first,
+// key column - query column + bcol0) with by_first / bcol0 wave-uniform: a sum along diagonals.  Per key block the wave writes its
+// dS tile to LDS as [query][36 floats: 8 zeros, 16 key columns, zeros] (one ds_write_b128 per lane, bank-balanced), and lane L < 46 adds
+// the diagonal L % 23 of query row L / 23 (8 unpredicated reads at constant offsets: the zero margins absorb the ends) into a register
+// per key block.  Those 8 registers collect over the workgroup's tiles while (by_first, bcol0) stays the same -- every interior tile --
+// and go to the workgroup's bins (LDS atomics), then to global memory, once.
+#define NM_DS_STRIDE 36
+#define NM_DS_WAVE (16 * NM_DS_STRIDE)
+
+template <int K>
+__device__ __forceinline__ void nm_drpb_flush(float* dbin, const float (&bacc)[K + 1], int by_first, int bcol0) {
+    constexpr int RB = 2 * K - 1, NKT = K + 1, NBIN = 2 * (16 + 7);
+    const int lane = threadIdx.x & 63;
+    const int bq = lane / 23, bslot = lane - bq * 23;
+    const int col = bslot - 7 + bcol0;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int row = by_first - bq + kt;
+        if (lane < NBIN && (unsigned)row < (unsigned)RB && (unsigned)col < (unsigned)RB && bacc[kt] != 0.f) atomicAdd(&dbin[row * RB + col], bacc[kt]);
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(512) void na2d_mfma_bwd_q_kernel(Na2d p) {
     typedef NmGeom<K> G;
-    constexpr int NS = G::NS, RB = G::RB, NKT = G::NKT, HWP = G::HWP, NBIN = 2 * (16 + 7);
-    __shared__ __attribute__((aligned(16))) unsigned char ks[G::NPOS * 64];
-    __shared__ __attribute__((aligned(16))) unsigned char vs[G::NPOS * 64];
-    __shared__ __attribute__((aligned(16))) float tab[G::TAB];
-    __shared__ __attribute__((aligned(16))) float dsbuf[8][256];           // per wave: dS of one key block as [query][key column]
-    __shared__ float dbin[RB * RB];
-    const int h = blockIdx.z % p.nH, b = blockIdx.z / p.nH;
-    const int ry = blockIdx.y % p.d, rx = blockIdx.x % p.d;
-    const int py0 = (blockIdx.y / p.d) * NM_TH, px0 = (blockIdx.x / p.d) * NM_TW;
-    const int Ly = (p.H - ry + p.d - 1) / p.d, Lx = (p.W - rx + p.d - 1) / p.d;
-    if (py0 >= Ly || px0 >= Lx) return;
+    constexpr int RB = G::RB, NKT = G::NKT, HWP = G::HWP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynq[];
+    unsigned char* ks = dynq;
+    unsigned char* vs = ks + G::NPOS * 64;
+    float* tab = (float*)(vs + G::NPOS * 64);
+    float* dsbuf = tab + G::TAB;                                           // [8 waves][16 queries][36]
+    float* dbin = dsbuf + 8 * NM_DS_WAVE;                                  // [RB * RB]
+    const NmWork w = nm_work(p);
     const int C = p.nH * 32;
-    const int hsy = clampi(py0 - NS, 0, Ly - K), hey = clampi(min(py0 + NM_TH, Ly) - 1 - NS, 0, Ly - K) + K;
-    const int hsx = clampi(px0 - NS, 0, Lx - K), hex = clampi(min(px0 + NM_TW, Lx) - 1 - NS, 0, Lx - K) + K;
-    nm_bias_table<K>(tab, p.rpb, h);
-    for (int i = threadIdx.x; i < RB * RB; i += 512) dbin[i] = 0.f;
-    nm_stage<G::NPOS, HWP>(ks, p.qkv + C + h * 32, 3L * C, p, b, ry, rx, hsy, hsx, hey - hsy, hex - hsx);
-    nm_stage<G::NPOS, HWP>(vs, p.qkv + 2 * C + h * 32, 3L * C, p, b, ry, rx, hsy, hsx, hey - hsy, hex - hsx);
-    __syncthreads();
-    const NmQuery q = nm_query<K>(p, b, h, ry, rx, py0, px0, Ly, Lx, hsy, hsx);
+    const unsigned colstride = p.d * 3 * C, rowstride = colstride * p.W;
+    const bf16* qkv_b = p.qkv + (long)w.b * p.H * p.W * 3 * C + w.h * 32;
+    const bf16* out_b = p.out + (long)w.b * p.H * p.W * C + w.h * 32;
+    const bf16* dout_b = p.dout + (long)w.b * p.H * p.W * C + w.h * 32;
+    bf16* dq_b = p.dqkv + (long)w.b * p.H * p.W * 3 * C + w.h * 32;
+    const float* lse_b = p.lse + ((long)w.b * p.nH + w.h) * p.H * p.W;
+    float* delta_b = p.delta + ((long)w.b * p.nH + w.h) * p.H * p.W;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
-    if (q.wave_active) {
-        const bf16x8 qf = *(const bf16x8*)(p.qkv + q.pix * 3 * C + h * 32 + 8 * fg);
-        const bf16x8 dof = *(const bf16x8*)(p.dout + q.pix * C + h * 32 + 8 * fg);
-        float delta;
-        {
-            const bf16x8 ov = *(const bf16x8*)(p.out + q.pix * C + h * 32 + 8 * fg);
-            float part = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float sc = p.scale * LOG2E;
+    nm_bias_table<K>(tab, p.rpb, w.h);
+    for (int i = threadIdx.x; i < 8 * NM_DS_WAVE + RB * RB; i += 512) dsbuf[i] = 0.f;       // (dbin follows dsbuf)
+    float* buf = dsbuf + wave * NM_DS_WAVE;
+    const int bq = lane / 23, bslot = lane - bq * 23;
+    const float* bread = buf + (bq & 1) * 8 * NM_DS_STRIDE + bslot + 1;                      // + qx * 37: element (query bq * 8 + qx, column bslot - 7 + qx)
+    float* bwrite = buf + fr * NM_DS_STRIDE + 8 + 4 * fg;
+    float bacc[NKT];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) part += (float)dof[c] * (float)ov[c];
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            delta = part;
-        }
-        const float lse2 = p.lse[q.si] * LOG2E;
-        if (q.valid && fg == 0) p.delta[q.si] = delta;
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        const float sc = p.scale * LOG2E;
-        bool colok[4];
+    for (int kt = 0; kt < NKT; ++kt) bacc[kt] = 0.f;
+    int acc_by = 0, acc_bc = 0;
+    bool acc_any = false;
+    NmStage<G::NPOS, HWP, G::NIT> st;
+    NmTile g = nm_tile_q<K>(p, w, w.t0);
+    auto issue = [&](const NmTile& t) {
+        st.issue(t, qkv_b + ((unsigned)(t.hsy * p.d + t.ry) * p.W + t.hsx * p.d + t.rx) * (unsigned)(3 * C) + C, C, rowstride, colstride);
+    };
+    issue(g);
+    for (int t = w.t0; t < w.t1; ++t) {
+        __syncthreads();
+        st.commit(ks, vs);
+        __syncthreads();
+        // this tile's own global operands before the prefetch (loads return in order)
+        const NmQuery q = nm_query<K>(p, g);
+        const bf16x8 qf = *(const bf16x8*)(qkv_b + q.pix * (unsigned)(3 * C) + 8 * fg);
+        const bf16x8 dof = *(const bf16x8*)(dout_b + q.pix * (unsigned)C + 8 * fg);
+        const bf16x8 ov = *(const bf16x8*)(out_b + q.pix * (unsigned)C + 8 * fg);
+        const float lse2 = lse_b[q.pix] * LOG2E;
+        NmTile gn = g;
+        if (t + 1 < w.t1) { gn = nm_tile_q<K>(p, w, t + 1); issue(gn); }
+        if (g.ok && q.wave_active) {
+            float delta = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) colok[r] = q.valid && (unsigned)(4 * fg + r - q.dx0) < (unsigned)K;
-        // drpb: lane L < 46 sums the diagonal `slot` = key column - query column + 7 of query row L / 23, per key block
-        const int bq = lane / 23, bslot = lane - bq * 23;
-        float* buf = dsbuf[wave];
-        float bacc[NKT];
-        f32x4 ds[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const f32x4 sv = mfma16(frag_rows(ks, q.r0 + kt * HWP, fr, fg), qf, zero4);
-            const f32x4 dp = mfma16(frag_rows(vs, q.r0 + kt * HWP, fr, fg), dof, zero4);
-            const f32x4 bias = nm_bias4(tab, RB, clampi(q.by0 + kt, 0, RB - 1), q.j0);
-            const bool rowok = (unsigned)(kt - q.dy0) < (unsigned)K;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = (rowok && colok[r]) ? fast_exp2(sv[r] * sc + bias[r] - lse2) : 0.f;
-                ds[kt][r] = pr * (dp[r] - delta);
-            }
+            for (int c = 0; c < 8; ++c) delta += (float)dof[c] * (float)ov[c];
+            delta += __shfl_xor(delta, 16);
+            delta += __shfl_xor(delta, 32);
+            if (q.valid && fg == 0) delta_b[q.pix] = delta;
             if (p.drpb) {
-                *(f32x4*)(buf + fr * 16 + 4 * fg) = ds[kt];
-                __builtin_amdgcn_wave_barrier();
-                float a = 0.f;
+                const int by_first = __builtin_amdgcn_readfirstlane(q.by0);       // lane 0 = the wave's first query (row 0, column 0)
+                const int bc_first = __builtin_amdgcn_readfirstlane(q.bcol0);
+                if (acc_any && (by_first != acc_by || bc_first != acc_bc)) {
+                    nm_drpb_flush<K>(dbin, bacc, acc_by, acc_bc);
 #pragma unroll
-                for (int qx = 0; qx < 8; ++qx) {
-                    const int c = bslot - 7 + qx;
-                    const float v = buf[(((bq & 1) * 8 + qx) * 16 + (c & 15))];
-                    a += (lane < NBIN && (unsigned)c < 16u) ? v : 0.f;
+                    for (int kt = 0; kt < NKT; ++kt) bacc[kt] = 0.f;
                 }
-                bacc[kt] = a;
-                __builtin_amdgcn_wave_barrier();
+                acc_by = by_first; acc_bc = bc_first; acc_any = true;
+            }
+            bool colok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) colok[r] = q.valid && (unsigned)(4 * fg + r - q.dx0) < (unsigned)K;
+            f32x4 o[2] = {zero4, zero4};
+#pragma unroll
+            for (int s2 = 0; s2 < NKT / 2; ++s2) {
+                bf16x8 pb;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kt = 2 * s2 + u;
+                    const f32x4 sv = mfma16(nm_rows<HWP>(ks, q.a_rows, kt), qf, zero4);
+                    const f32x4 dp = mfma16(nm_rows<HWP>(vs, q.a_rows, kt), dof, zero4);
+                    const f32x4 bias = nm_bias4(tab, clampi(q.by0 + kt, 0, RB - 1), q.boff);
+                    const bool rowok = (unsigned)(kt - q.dy0) < (unsigned)K;
+                    f32x4 ds4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // (masked through the exponent: a select of the RESULT makes the compiler branch around the exp and its operands)
+                        const float e = fast_exp2((rowok && colok[r]) ? sv[r] * sc + bias[r] - lse2 : NEG_BIG);
+                        ds4[r] = e * (dp[r] - delta);
+                        pb[4 * u + r] = (bf16)ds4[r];
+                    }
+                    if (p.drpb) {
+                        *(f32x4*)bwrite = ds4;
+                        __builtin_amdgcn_wave_barrier();
+                        float a = 0.f;
+#pragma unroll
+                        for (int qx = 0; qx < 8; ++qx) a += bread[qx * (NM_DS_STRIDE + 1)];
+                        bacc[kt] += a;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma16(nm_tr<HWP>(ks, q.a_tr[dt], 2 * s2), pb, o[dt]);
+            }
+            if (q.valid) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) nm_store4(dq_b + q.pix * (unsigned)(3 * C) + dt * 16 + 4 * fg, o[dt], p.scale);
             }
         }
-        f32x4 o[2] = {zero4, zero4};
-#pragma unroll
-        for (int s2 = 0; s2 < NKT / 2; ++s2) {
-            bf16x8 pb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pb[r] = (bf16)ds[2 * s2][r]; pb[4 + r] = (bf16)ds[2 * s2 + 1][r]; }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                o[dt] = mfma16(frag_tr(ks, q.r0 + 2 * s2 * HWP, q.r0 + (2 * s2 + 1) * HWP, dt * 16, lane), pb, o[dt]);
-        }
-        if (q.valid) {
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) nm_store4(p.dqkv + q.pix * 3 * C + h * 32 + dt * 16 + 4 * fg, o[dt], p.scale);
-        }
-        if (p.drpb && lane < NBIN) {
-            // bias row of key block kt for query row bq: by0 is this wave's value for ITS first query row (lane 0), one less per row
-            const int by_first = __shfl(q.by0, 0), j_first = __shfl(q.j0, 0);      // lane 0: query (row 0, column 0), fg = 0
-            const int col = bslot - 7 + j_first;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const int row = by_first - bq + kt;
-                if ((unsigned)row < (unsigned)RB && (unsigned)col < (unsigned)RB && bacc[kt] != 0.f) atomicAdd(&dbin[row * RB + col], bacc[kt]);
-            }
-        }
+        g = gn;
     }
     if (p.drpb) {
+        if (acc_any) nm_drpb_flush<K>(dbin, bacc, acc_by, acc_bc);
         __syncthreads();
         for (int i = threadIdx.x; i < RB * RB; i += 512)
-            if (dbin[i] != 0.f) atomicAdd(p.drpb + h * RB * RB + i, dbin[i]);
+            if (dbin[i] != 0.f) atomicAdd(p.drpb + w.h * RB * RB + i, dbin[i]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward per key: dk, dv.  Tile of 8 x 16 KEY positions; q, dout, (lse, delta) of the tile's inverse neighbourhood in LDS
-// (extents hh_max x hw_max from the launcher, as in na2d_bwd_kv_tiled_kernel).
+// (extents hh_max x hw_max from the launcher: T + K + K/2 - 1 positions per axis beside a border, the whole class when it is short).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ int inv_start(int pos) { return pos < K ? 0 : pos - K / 2; }
-template <int K>
-__device__ __forceinline__ int inv_end(int pos, int L) { return pos >= L - K ? L : pos + K / 2 + 1; }
+// bias table of the per-key kernel: [key row - query row + K - 1 + KV_PR][key column - query column + K - 1 + KV_PC], zero margins wide
+// enough for every (key, query) pair a wave forms with the padded blocks of its query region, so the index needs no clamp
+#define KV_PR 4
+#define KV_PC 25
+#define KV_ST 48
+#define KV_ROWS(K) (2 * (K) - 1 + 2 * KV_PR)
 
 template <int K>
 __global__ __launch_bounds__(512) void na2d_mfma_bwd_kv_kernel(Na2d p) {
-    constexpr int RB = 2 * K - 1, NS = K / 2;
+    constexpr int RB = 2 * K - 1;
     const int HWQ = p.hw_max, NPOS = p.hh_max * p.hw_max + 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     unsigned char* qs = dyn;                                  // [NPOS] x 64 B
     unsigned char* gs = qs + NPOS * 64;                       // [NPOS] x 64 B
     float2* ld = (float2*)(gs + NPOS * 64);                   // [NPOS] (lse * log2e, delta)
-    float* rpb = (float*)(ld + NPOS);                         // [RB * RB]
-    const int h = blockIdx.z % p.nH, b = blockIdx.z / p.nH;
-    const int ry = blockIdx.y % p.d, rx = blockIdx.x % p.d;
-    const int py0 = (blockIdx.y / p.d) * NM_TH, px0 = (blockIdx.x / p.d) * NM_TW;
-    const int Ly = (p.H - ry + p.d - 1) / p.d, Lx = (p.W - rx + p.d - 1) / p.d;
-    if (py0 >= Ly || px0 >= Lx) return;
+    float* rpb = (float*)(ld + NPOS);                         // [KV_ROWS][KV_ST]
+    const NmWork w = nm_work(p);
     const int C = p.nH * 32;
-    const int pyl = min(py0 + NM_TH, Ly) - 1, pxl = min(px0 + NM_TW, Lx) - 1;          // last key of the tile
-    const int hsy = inv_start<K>(py0), hey = inv_end<K>(pyl, Ly);
-    const int hsx = inv_start<K>(px0), hex = inv_end<K>(pxl, Lx);
-    const int hh = hey - hsy, hw = hex - hsx;
-    for (int i = threadIdx.x; i < RB * RB; i += 512) rpb[i] = p.rpb ? p.rpb[h * RB * RB + i] * LOG2E : 0.f;
-    for (int i = threadIdx.x; i < NPOS * 4; i += 512) {
-        const int c = i & 3, pos = i >> 2;
-        const int yy = pos / HWQ, xx = pos - yy * HWQ;
-        u32x4 vq = {0u, 0u, 0u, 0u}, vg = vq;
-        float2 st = {0.f, 0.f};
-        if (yy < hh && xx < hw) {
-            const int gy = (hsy + yy) * p.d + ry, gx = (hsx + xx) * p.d + rx;
-            const long gp = ((long)b * p.H + gy) * p.W + gx;
-            vq = *(const u32x4*)(p.qkv + gp * 3 * C + h * 32 + c * 8);
-            vg = *(const u32x4*)(p.dout + gp * C + h * 32 + c * 8);
-            if (c == 0) {
-                const long si = (((long)b * p.nH + h) * p.H + gy) * p.W + gx;
-                st.x = p.lse[si] * LOG2E; st.y = p.delta[si];
-            }
-        }
-        *(u32x4*)(qs + rm_off(pos, c)) = vq;
-        *(u32x4*)(gs + rm_off(pos, c)) = vg;
-        if (c == 0) ld[pos] = st;
-    }
-    __syncthreads();
+    const unsigned colq = p.d * 3 * C, rowq = colq * p.W, colg = p.d * C, rowg = colg * p.W, cols = p.d, rows = p.d * p.W;
+    const bf16* qkv_b = p.qkv + (long)w.b * p.H * p.W * 3 * C + w.h * 32;
+    const bf16* dout_b = p.dout + (long)w.b * p.H * p.W * C + w.h * 32;
+    bf16* dqkv_b = p.dqkv + (long)w.b * p.H * p.W * 3 * C + w.h * 32;
+    const float* lse_b = p.lse + ((long)w.b * p.nH + w.h) * p.H * p.W;
+    const float* delta_b = p.delta + ((long)w.b * p.nH + w.h) * p.H * p.W;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
     const int wy = wave >> 1, wx = wave & 1;
-    if (py0 + 2 * wy >= Ly || px0 + 8 * wx >= Lx) return;     // whole waves
-    const int kyr = py0 + 2 * wy + (fr >> 3), kxr = px0 + 8 * wx + (fr & 7);
-    const bool kvalid = kyr < Ly && kxr < Lx;
-    const int ky = min(kyr, Ly - 1), kx = min(kxr, Lx - 1);
-    const long pix = ((long)b * p.H + ky * p.d + ry) * p.W + kx * p.d + rx;
-    const bf16x8 kf = *(const bf16x8*)(p.qkv + pix * 3 * C + C + h * 32 + 8 * fg);
-    const bf16x8 vf = *(const bf16x8*)(p.qkv + pix * 3 * C + 2 * C + h * 32 + 8 * fg);
-    // the wave's query region (wave-uniform): union of the inverse neighbourhoods of its keys
-    const int ky_a = min(py0 + 2 * wy, Ly - 1), ky_b = min(py0 + 2 * wy + 1, Ly - 1);
-    const int kx_a = min(px0 + 8 * wx, Lx - 1), kx_b = min(px0 + 8 * wx + 7, Lx - 1);
-    const int qy0 = inv_start<K>(ky_a), qy1 = inv_end<K>(ky_b, Ly);
-    const int qx0 = inv_start<K>(kx_a), qx1 = inv_end<K>(kx_b, Lx);
-    const int ncb = (qx1 - qx0 + 15) >> 4, nblk = (qy1 - qy0) * ncb;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const float sc = p.scale * LOG2E;
-    f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
-    for (int j = 0; j < nblk; j += 2) {
-        int r0[2];
-        f32x4 pr[2], ds[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const bool real = j + u < nblk;
-            const int blk = real ? j + u : 0;
-            const int row = blk / ncb, cb = blk - row * ncb;
-            const int qy = qy0 + row, bx = qx0 + 16 * cb;
-            r0[u] = (qy - hsy) * HWQ + (bx - hsx);
-            const f32x4 sv = mfma16(frag_rows(qs, r0[u], fr, fg), kf, zero4);
-            const f32x4 dp = mfma16(frag_rows(gs, r0[u], fr, fg), vf, zero4);
-            const int syq = clampi(qy - NS, 0, Ly - K);
-            const bool rowok = real && (unsigned)(ky - syq) < (unsigned)K;
-            const int brow = clampi(ky - qy + K - 1, 0, RB - 1) * RB;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qx = bx + 4 * fg + r;
-                const int sxq = clampi(qx - NS, 0, Lx - K);
-                const bool ok = rowok && qx < qx1 && (unsigned)(kx - sxq) < (unsigned)K;
-                const float2 st = ld[r0[u] + 4 * fg + r];
-                const float bias = rpb[brow + clampi(kx - qx + K - 1, 0, RB - 1)];
-                pr[u][r] = ok ? fast_exp2(sv[r] * sc + bias - st.x) : 0.f;
-                ds[u][r] = pr[u][r] * (dp[r] - st.y);
+    for (int i = threadIdx.x; i < KV_ROWS(K) * KV_ST; i += 512) {
+        const int row = i / KV_ST - KV_PR, col = i % KV_ST - KV_PC;
+        rpb[i] = (p.rpb != nullptr && (unsigned)row < (unsigned)RB && (unsigned)col < (unsigned)RB) ? p.rpb[(w.h * RB + row) * RB + col] * LOG2E : 0.f;
+    }
+    const float inv_hwq = 1.0f / (float)HWQ;
+    const int c = threadIdx.x & 3;
+    for (int t = w.t0; t < w.t1; ++t) {
+        const NmTile g = nm_tile_kv<K>(p, w, t);
+        __syncthreads();                                       // the previous tile's LDS reads are done
+        {
+            const unsigned pix0 = (unsigned)(g.hsy * p.d + g.ry) * p.W + g.hsx * p.d + g.rx;
+            for (int pos = threadIdx.x >> 2; pos < NPOS; pos += 128) {
+                const int yy = fdiv(pos, inv_hwq), xx = pos - yy * HWQ;
+                u32x4 vq = {0u, 0u, 0u, 0u}, vg = vq;
+                float2 st = {0.f, 0.f};
+                if (g.ok && yy < g.hh && xx < g.hw) {
+                    vq = *(const u32x4*)(qkv_b + (pix0 * (unsigned)(3 * C) + (unsigned)yy * rowq + (unsigned)xx * colq + c * 8));
+                    vg = *(const u32x4*)(dout_b + (pix0 * (unsigned)C + (unsigned)yy * rowg + (unsigned)xx * colg + c * 8));
+                    if (c == 0) {
+                        const unsigned so = pix0 + (unsigned)yy * rows + (unsigned)xx * cols;
+                        st.x = lse_b[so] * LOG2E; st.y = delta_b[so];
+                    }
+                }
+                const int off = rm_off(pos, c);
+                *(u32x4*)(qs + off) = vq;
+                *(u32x4*)(gs + off) = vg;
+                if (c == 0) ld[pos] = st;
             }
         }
-        bf16x8 pb, db;
+        __syncthreads();
+        if (g.ok && g.py0 + 2 * wy < g.Ly && g.px0 + 8 * wx < g.Lx) {          // whole waves
+            const int kyr = g.py0 + 2 * wy + (fr >> 3), kxr = g.px0 + 8 * wx + (fr & 7);
+            const bool kvalid = kyr < g.Ly && kxr < g.Lx;
+            const int ky = min(kyr, g.Ly - 1), kx = min(kxr, g.Lx - 1);
+            const unsigned pix = (unsigned)(ky * p.d + g.ry) * p.W + kx * p.d + g.rx;
+            const bf16x8 kf = *(const bf16x8*)(qkv_b + pix * (unsigned)(3 * C) + C + 8 * fg);
+            const bf16x8 vf = *(const bf16x8*)(qkv_b + pix * (unsigned)(3 * C) + 2 * C + 8 * fg);
+            // a query attends this lane's key iff it lies in the key's inverse neighbourhood (exact, per axis)
+            const int qys_k = inv_start<K>(ky), qyn_k = inv_end<K>(ky, g.Ly) - qys_k;
+            const int qxs_k = inv_start<K>(kx), qxn_k = inv_end<K>(kx, g.Lx) - qxs_k;
+            // the wave's query region (wave-uniform): union of the inverse neighbourhoods of its keys
+            const int ky_a = min(g.py0 + 2 * wy, g.Ly - 1), ky_b = min(g.py0 + 2 * wy + 1, g.Ly - 1);
+            const int kx_a = min(g.px0 + 8 * wx, g.Lx - 1), kx_b = min(g.px0 + 8 * wx + 7, g.Lx - 1);
+            const int qy0 = inv_start<K>(ky_a), qy1 = inv_end<K>(ky_b, g.Ly);
+            const int qx0 = inv_start<K>(kx_a), qx1 = inv_end<K>(kx_b, g.Lx);
+            const int ncb = (qx1 - qx0 + 15) >> 4, nblk = (qy1 - qy0) * ncb;
+            f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+            for (int j = 0; j < nblk; j += 2) {
+                int r0[2];
+                f32x4 pr[2], ds[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pb[r] = (bf16)pr[0][r]; pb[4 + r] = (bf16)pr[1][r];
-            db[r] = (bf16)ds[0][r]; db[4 + r] = (bf16)ds[1][r];
+                for (int u = 0; u < 2; ++u) {
+                    const bool real = j + u < nblk;
+                    const int blk = real ? j + u : 0;
+                    const int row = ncb == 2 ? blk >> 1 : blk, cb = blk - row * ncb;
+                    const int qy = qy0 + row, bx = qx0 + 16 * cb;
+                    r0[u] = (qy - g.hsy) * HWQ + (bx - g.hsx);
+                    const f32x4 sv = mfma16(frag_rows(qs, r0[u], fr, fg), kf, zero4);
+                    const f32x4 dp = mfma16(frag_rows(gs, r0[u], fr, fg), vf, zero4);
+                    const bool rowok = real && (unsigned)(qy - qys_k) < (unsigned)qyn_k;
+                    const int cbase = bx + 4 * fg - qxs_k;                                      // query column 4 fg + r relative to the key's first query
+                    const float* brow = rpb + (ky - qy + K - 1 + KV_PR) * KV_ST + (kx - bx - 4 * fg + K - 1 + KV_PC) - 3;
+                    const float2* lrow = ld + r0[u] + 4 * fg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = rowok && (unsigned)(cbase + r) < (unsigned)qxn_k;
+                        const float2 stq = lrow[r];
+                        const float arg = sv[r] * sc + brow[3 - r] - stq.x;                  // loads outside the select: no branch around them
+                        pr[u][r] = fast_exp2(ok ? arg : NEG_BIG);
+                        ds[u][r] = pr[u][r] * (dp[r] - stq.y);
+                    }
+                }
+                bf16x8 pb, db;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pb[r] = (bf16)pr[0][r]; pb[4 + r] = (bf16)pr[1][r];
+                    db[r] = (bf16)ds[0][r]; db[4 + r] = (bf16)ds[1][r];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = mfma16(frag_tr(gs, r0[0], r0[1], dt * 16, lane), pb, dv[dt]);
+                    dk[dt] = mfma16(frag_tr(qs, r0[0], r0[1], dt * 16, lane), db, dk[dt]);
+                }
+            }
+            if (kvalid) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    nm_store4(dqkv_b + pix * (unsigned)(3 * C) + C + dt * 16 + 4 * fg, dk[dt], p.scale);
+                    nm_store4(dqkv_b + pix * (unsigned)(3 * C) + 2 * C + dt * 16 + 4 * fg, dv[dt], 1.0f);
+                }
+            }
         }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = mfma16(frag_tr(gs, r0[0], r0[1], dt * 16, lane), pb, dv[dt]);
-            dk[dt] = mfma16(frag_tr(qs, r0[0], r0[1], dt * 16, lane), db, dk[dt]);
-        }
-    }
-    if (!kvalid) return;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        nm_store4(p.dqkv + pix * 3 * C + C + h * 32 + dt * 16 + 4 * fg, dk[dt], p.scale);
-        nm_store4(p.dqkv + pix * 3 * C + 2 * C + h * 32 + dt * 16 + 4 * fg, dv[dt], 1.0f);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
-static dim3 nm_grid(const Na2d& p) {
+static dim3 nm_plan(Na2d& p) {
     const int Lx = (p.W + p.d - 1) / p.d, Ly = (p.H + p.d - 1) / p.d;      // the longest residue class
-    return dim3(((Lx + NM_TW - 1) / NM_TW) * p.d, ((Ly + NM_TH - 1) / NM_TH) * p.d, p.B * p.nH);
+    p.tiles_x = (Lx + NM_TW - 1) / NM_TW; p.tiles_y = (Ly + NM_TH - 1) / NM_TH;
+    p.inv_tiles_x = 1.0f / (float)p.tiles_x;
+    const int per_class = p.tiles_x * p.tiles_y;
+    const long total = (long)per_class * p.d * p.d * p.B * p.nH;
+    // tiles per workgroup: enough workgroups for ~6 per CU, at most 8 tiles each, never more than a class has
+    int nt = (int)(total / 1536);
+    nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+    if (nt > per_class) nt = per_class;
+    const char* ev = getenv("UENC_NA2D_NT");
+    if (ev && atoi(ev) > 0) nt = atoi(ev);
+    p.nt = nt;
+    return dim3((per_class + nt - 1) / nt, p.d * p.d, p.B * p.nH);
 }
 
-int na2d_mfma_fwd(const Na2d& p, int K, hipStream_t stream) {
-    const dim3 grid = nm_grid(p);
-    UENC_CHECK_ARG(grid.y <= 65535);
+int na2d_mfma_fwd(const Na2d& p0, int K, hipStream_t stream) {
+    Na2d p = p0;
+    const dim3 grid = nm_plan(p);
+    UENC_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535);
     switch (K) {
         case 3: hipLaunchKernelGGL(na2d_mfma_fwd_kernel<3>, grid, dim3(512), 0, stream, p); break;
         case 5: hipLaunchKernelGGL(na2d_mfma_fwd_kernel<5>, grid, dim3(512), 0, stream, p); break;
@@ -422,14 +594,25 @@ int na2d_mfma_fwd(const Na2d& p, int K, hipStream_t stream) {
     UENC_LAUNCH_RET();
 }
 
-template <int K>
-static int nm_launch_kv(Na2d& p, const dim3& grid, hipStream_t stream) {
-    // inverse-neighbourhood extent per axis: T + K + K/2 - 1 beside one border; a class shorter than T + 2K - 1 can touch both
+// inverse-neighbourhood extent per axis: T + K + K/2 - 1 beside one border; a class shorter than T + 2K - 1 can touch both
+static void nm_kv_extents(Na2d& p, int K) {
     const int Lx = (p.W + p.d - 1) / p.d, Ly = (p.H + p.d - 1) / p.d;
     p.hh_max = Ly >= NM_TH + 2 * K - 1 ? NM_TH + K + K / 2 - 1 : (Ly < NM_TH + 2 * K - 2 ? Ly : NM_TH + 2 * K - 2);
     p.hw_max = Lx >= NM_TW + 2 * K - 1 ? NM_TW + K + K / 2 - 1 : (Lx < NM_TW + 2 * K - 2 ? Lx : NM_TW + 2 * K - 2);
+}
+
+bool na2d_mfma_supported(int H, int W, int nH, int K, int dilation) {
+    if (K > 7 || (long)H * W * 3 * nH * 32 >= (1L << 31)) return false;
+    Na2d p = {};
+    p.H = H; p.W = W; p.d = dilation;
+    nm_kv_extents(p, K);
+    return true;
+}
+
+template <int K>
+static int nm_launch_kv(Na2d& p, const dim3& grid, hipStream_t stream) {
     const int npos = p.hh_max * p.hw_max + 32;
-    const int shm = npos * (64 + 64 + 8) + (2 * K - 1) * (2 * K - 1) * 4;
+    const int shm = npos * (64 + 64 + 8) + KV_ROWS(K) * KV_ST * 4;
     static int attr = 0;
     if (attr < shm) {
         const hipError_t e = hipFuncSetAttribute((const void*)na2d_mfma_bwd_kv_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
@@ -440,14 +623,29 @@ static int nm_launch_kv(Na2d& p, const dim3& grid, hipStream_t stream) {
     return UENC_OK;
 }
 
+template <int K>
+static int nm_launch_q(Na2d& p, const dim3& grid, hipStream_t stream) {
+    typedef NmGeom<K> G;
+    const int shm = 2 * G::NPOS * 64 + (G::TAB + 8 * NM_DS_WAVE + G::RB * G::RB) * 4;
+    static bool attr = false;
+    if (!attr) {
+        const hipError_t e = hipFuncSetAttribute((const void*)na2d_mfma_bwd_q_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(na2d_mfma_bwd_q_kernel<K>, grid, dim3(512), shm, stream, p);
+    return UENC_OK;
+}
+
 int na2d_mfma_bwd(Na2d& p, int K, hipStream_t stream) {
-    const dim3 grid = nm_grid(p);
-    UENC_CHECK_ARG(grid.y <= 65535);
+    const dim3 grid = nm_plan(p);
+    UENC_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535);
+    nm_kv_extents(p, K);
     int rc;
     switch (K) {
-        case 3: hipLaunchKernelGGL(na2d_mfma_bwd_q_kernel<3>, grid, dim3(512), 0, stream, p); rc = nm_launch_kv<3>(p, grid, stream); break;
-        case 5: hipLaunchKernelGGL(na2d_mfma_bwd_q_kernel<5>, grid, dim3(512), 0, stream, p); rc = nm_launch_kv<5>(p, grid, stream); break;
-        case 7: hipLaunchKernelGGL(na2d_mfma_bwd_q_kernel<7>, grid, dim3(512), 0, stream, p); rc = nm_launch_kv<7>(p, grid, stream); break;
+        case 3: rc = nm_launch_q<3>(p, grid, stream); if (rc == UENC_OK) rc = nm_launch_kv<3>(p, grid, stream); break;
+        case 5: rc = nm_launch_q<5>(p, grid, stream); if (rc == UENC_OK) rc = nm_launch_kv<5>(p, grid, stream); break;
+        case 7: rc = nm_launch_q<7>(p, grid, stream); if (rc == UENC_OK) rc = nm_launch_kv<7>(p, grid, stream); break;
         default: return UENC_EINVAL;
     }
     if (rc != UENC_OK) return rc;
