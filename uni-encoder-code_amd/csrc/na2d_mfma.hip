@@ -446,7 +446,9 @@ __global__ __launch_bounds__(512) void na2d_mfma_bwd_q_kernel(Na2d p) {
 #define KV_ST 48
 #define KV_ROWS(K) (2 * (K) - 1 + 2 * KV_PR)
 
-template <int K>
+#define NM_KV_PF_NIT 3       // prefetching form: halo positions + 32 <= 3 * 128
+
+template <int K, bool PF>
 __global__ __launch_bounds__(512) void na2d_mfma_bwd_kv_kernel(Na2d p) {
     constexpr int RB = 2 * K - 1;
     const int HWQ = p.hw_max, NPOS = p.hh_max * p.hw_max + 32;
@@ -473,37 +475,61 @@ __global__ __launch_bounds__(512) void na2d_mfma_bwd_kv_kernel(Na2d p) {
     }
     const float inv_hwq = 1.0f / (float)HWQ;
     const int c = threadIdx.x & 3;
+    // staging: q and dout chunks and (chunk-0 lanes) the statistics of halo position (tid >> 2) + 128 it; zero outside the halo.
+    // PF: the loads of tile t + 1 are issued before the arithmetic of tile t and committed to LDS after it (3 passes in registers).
+    constexpr int NIT = PF ? NM_KV_PF_NIT : 1;
+    u32x4 sq[NIT], sg[NIT];
+    float2 sst[NIT];
+    auto load_pos = [&](const NmTile& t, unsigned pix0, int pos, u32x4& vq, u32x4& vg, float2& st) {
+        const int yy = fdiv(pos, inv_hwq), xx = pos - yy * HWQ;
+        vq = (u32x4){0u, 0u, 0u, 0u}; vg = vq; st = (float2){0.f, 0.f};
+        if (t.ok && pos < NPOS && yy < t.hh && xx < t.hw) {
+            vq = *(const u32x4*)(qkv_b + (pix0 * (unsigned)(3 * C) + (unsigned)yy * rowq + (unsigned)xx * colq + c * 8));
+            vg = *(const u32x4*)(dout_b + (pix0 * (unsigned)C + (unsigned)yy * rowg + (unsigned)xx * colg + c * 8));
+            if (c == 0) {
+                const unsigned so = pix0 + (unsigned)yy * rows + (unsigned)xx * cols;
+                st.x = lse_b[so] * LOG2E; st.y = delta_b[so];
+            }
+        }
+    };
+    auto store_pos = [&](int pos, const u32x4& vq, const u32x4& vg, const float2& st) {
+        if (pos < NPOS) {
+            const int off = rm_off(pos, c);
+            *(u32x4*)(qs + off) = vq;
+            *(u32x4*)(gs + off) = vg;
+            if (c == 0) ld[pos] = st;
+        }
+    };
+    auto issue = [&](const NmTile& t) {
+        const unsigned pix0 = (unsigned)(t.hsy * p.d + t.ry) * p.W + t.hsx * p.d + t.rx;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) load_pos(t, pix0, (threadIdx.x >> 2) + it * 128, sq[it], sg[it], sst[it]);
+    };
+    NmTile g = nm_tile_kv<K>(p, w, w.t0);
+    if (PF) issue(g);
     for (int t = w.t0; t < w.t1; ++t) {
-        const NmTile g = nm_tile_kv<K>(p, w, t);
         __syncthreads();                                       // the previous tile's LDS reads are done
-        {
+        if (PF) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) store_pos((threadIdx.x >> 2) + it * 128, sq[it], sg[it], sst[it]);
+        } else {
             const unsigned pix0 = (unsigned)(g.hsy * p.d + g.ry) * p.W + g.hsx * p.d + g.rx;
             for (int pos = threadIdx.x >> 2; pos < NPOS; pos += 128) {
-                const int yy = fdiv(pos, inv_hwq), xx = pos - yy * HWQ;
-                u32x4 vq = {0u, 0u, 0u, 0u}, vg = vq;
-                float2 st = {0.f, 0.f};
-                if (g.ok && yy < g.hh && xx < g.hw) {
-                    vq = *(const u32x4*)(qkv_b + (pix0 * (unsigned)(3 * C) + (unsigned)yy * rowq + (unsigned)xx * colq + c * 8));
-                    vg = *(const u32x4*)(dout_b + (pix0 * (unsigned)C + (unsigned)yy * rowg + (unsigned)xx * colg + c * 8));
-                    if (c == 0) {
-                        const unsigned so = pix0 + (unsigned)yy * rows + (unsigned)xx * cols;
-                        st.x = lse_b[so] * LOG2E; st.y = delta_b[so];
-                    }
-                }
-                const int off = rm_off(pos, c);
-                *(u32x4*)(qs + off) = vq;
-                *(u32x4*)(gs + off) = vg;
-                if (c == 0) ld[pos] = st;
+                load_pos(g, pix0, pos, sq[0], sg[0], sst[0]);
+                store_pos(pos, sq[0], sg[0], sst[0]);
             }
         }
         __syncthreads();
+        // this tile's own global operands before the prefetch (loads return in order)
+        const int kyr = g.py0 + 2 * wy + (fr >> 3), kxr = g.px0 + 8 * wx + (fr & 7);
+        const bool kvalid = kyr < g.Ly && kxr < g.Lx;
+        const int ky = clampi(kyr, 0, g.Ly - 1), kx = clampi(kxr, 0, g.Lx - 1);
+        const unsigned pix = (unsigned)(ky * p.d + g.ry) * p.W + kx * p.d + g.rx;
+        const bf16x8 kf = *(const bf16x8*)(qkv_b + pix * (unsigned)(3 * C) + C + 8 * fg);
+        const bf16x8 vf = *(const bf16x8*)(qkv_b + pix * (unsigned)(3 * C) + 2 * C + 8 * fg);
+        NmTile gn = g;
+        if (t + 1 < w.t1) { gn = nm_tile_kv<K>(p, w, t + 1); if (PF) issue(gn); }
         if (g.ok && g.py0 + 2 * wy < g.Ly && g.px0 + 8 * wx < g.Lx) {          // whole waves
-            const int kyr = g.py0 + 2 * wy + (fr >> 3), kxr = g.px0 + 8 * wx + (fr & 7);
-            const bool kvalid = kyr < g.Ly && kxr < g.Lx;
-            const int ky = min(kyr, g.Ly - 1), kx = min(kxr, g.Lx - 1);
-            const unsigned pix = (unsigned)(ky * p.d + g.ry) * p.W + kx * p.d + g.rx;
-            const bf16x8 kf = *(const bf16x8*)(qkv_b + pix * (unsigned)(3 * C) + C + 8 * fg);
-            const bf16x8 vf = *(const bf16x8*)(qkv_b + pix * (unsigned)(3 * C) + 2 * C + 8 * fg);
             // a query attends this lane's key iff it lies in the key's inverse neighbourhood (exact, per axis)
             const int qys_k = inv_start<K>(ky), qyn_k = inv_end<K>(ky, g.Ly) - qys_k;
             const int qxs_k = inv_start<K>(kx), qxn_k = inv_end<K>(kx, g.Lx) - qxs_k;
@@ -559,6 +585,7 @@ __global__ __launch_bounds__(512) void na2d_mfma_bwd_kv_kernel(Na2d p) {
                 }
             }
         }
+        g = gn;
     }
 }
 
@@ -594,11 +621,23 @@ int na2d_mfma_fwd(const Na2d& p0, int K, hipStream_t stream) {
     UENC_LAUNCH_RET();
 }
 
-// inverse-neighbourhood extent per axis: T + K + K/2 - 1 beside one border; a class shorter than T + 2K - 1 can touch both
+// LDS extent of the per-key kernel: the largest inverse-neighbourhood halo over all tiles of all residue classes, per axis
+// (T + K - 1 positions for an interior tile, up to T + K + K/2 - 1 where a tile's last key is the first of the clamped border band)
+static int nm_axis_extent(int len, int d, int K, int T) {
+    int best = 0;
+    for (int r = 0; r < d && r < len; ++r) {
+        const int L = (len - r + d - 1) / d;
+        for (int p0 = 0; p0 < L; p0 += T) {
+            const int pl = (p0 + T < L ? p0 + T : L) - 1;
+            const int s = p0 < K ? 0 : p0 - K / 2, e = pl >= L - K ? L : pl + K / 2 + 1;
+            if (e - s > best) best = e - s;
+        }
+    }
+    return best;
+}
 static void nm_kv_extents(Na2d& p, int K) {
-    const int Lx = (p.W + p.d - 1) / p.d, Ly = (p.H + p.d - 1) / p.d;
-    p.hh_max = Ly >= NM_TH + 2 * K - 1 ? NM_TH + K + K / 2 - 1 : (Ly < NM_TH + 2 * K - 2 ? Ly : NM_TH + 2 * K - 2);
-    p.hw_max = Lx >= NM_TW + 2 * K - 1 ? NM_TW + K + K / 2 - 1 : (Lx < NM_TW + 2 * K - 2 ? Lx : NM_TW + 2 * K - 2);
+    p.hh_max = nm_axis_extent(p.H, p.d, K, NM_TH);
+    p.hw_max = nm_axis_extent(p.W, p.d, K, NM_TW);
 }
 
 bool na2d_mfma_supported(int H, int W, int nH, int K, int dilation) {
@@ -609,18 +648,25 @@ bool na2d_mfma_supported(int H, int W, int nH, int K, int dilation) {
     return true;
 }
 
+template <int K, bool PF>
+static int nm_launch_kv2(Na2d& p, const dim3& grid, int shm, hipStream_t stream) {
+    static int attr = 0;
+    if (attr < shm) {
+        const hipError_t e = hipFuncSetAttribute((const void*)na2d_mfma_bwd_kv_kernel<K, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+        if (e != hipSuccess) return (int)e;
+        attr = shm;
+    }
+    hipLaunchKernelGGL((na2d_mfma_bwd_kv_kernel<K, PF>), grid, dim3(512), shm, stream, p);
+    return UENC_OK;
+}
+
 template <int K>
 static int nm_launch_kv(Na2d& p, const dim3& grid, hipStream_t stream) {
     const int npos = p.hh_max * p.hw_max + 32;
     const int shm = npos * (64 + 64 + 8) + KV_ROWS(K) * KV_ST * 4;
-    static int attr = 0;
-    if (attr < shm) {
-        const hipError_t e = hipFuncSetAttribute((const void*)na2d_mfma_bwd_kv_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-        if (e != hipSuccess) return (int)e;
-        attr = shm;
-    }
-    hipLaunchKernelGGL(na2d_mfma_bwd_kv_kernel<K>, grid, dim3(512), shm, stream, p);
-    return UENC_OK;
+    const char* ev = getenv("UENC_NA2D_VARIANT");
+    const bool pf = npos <= NM_KV_PF_NIT * 128 && p.nt > 1 && ev && (atoi(ev) & 4);      // A/B only: the prefetching form needs 153 VGPRs (one workgroup per CU) and measured slower
+    return pf ? nm_launch_kv2<K, true>(p, grid, shm, stream) : nm_launch_kv2<K, false>(p, grid, shm, stream);
 }
 
 template <int K>
