@@ -57,3 +57,9 @@ for s, n in by_site.most_common(60):
 print("---- by (op, shape, site)")
 for (op, shp, dt, site), n in sorted(tally.items(), key=lambda x: -x[1])[:120]:
     print(f"{n:5d}  {op:28s} {str(shp):28s} {dt:9s} {site}")
+print("---- by bytes moved (numel x itemsize x count), top 50")
+import math
+def nbytes(shp, dt):
+    return math.prod(shp) * {"float32": 4, "bfloat16": 2, "bool": 1, "int64": 8, "uint8": 1, "float16": 2, "int32": 4}.get(dt, 4)
+for (op, shp, dt, site), n in sorted(tally.items(), key=lambda x: -nbytes(x[0][1], x[0][2]) * x[1])[:50]:
+    print(f"{nbytes(shp, dt) * n / 1e6:9.1f} MB {n:4d}  {op:28s} {str(shp):28s} {dt:9s} {site}")

@@ -58,6 +58,8 @@ class GradBuckets:
         if listen_ops:
             from . import ops
             ops.set_grad_listener(self.signal)
+            if self.world > 1:
+                ops.WGRADS.overlap_exchange()
 
     # ---- flat storage -----------------------------------------------------------------------
     def _layout(self, order: List[int]):

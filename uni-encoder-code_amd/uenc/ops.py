@@ -219,6 +219,9 @@ class WgradQueue:
     TOKENS_PER_ITEM = {256: 16384, 128: 4096}     # token range of one work item (128 / 64 k-steps of 64)
 
     def __init__(self):
+        ev = os.environ.get("UENC_WGRAD_FLUSH")
+        if ev:                                   # A/B knob: items of the 256-tile class per launch (the 128-tile class gets 4x)
+            self.FLUSH_ITEMS = {256: int(ev), 128: 4 * int(ev)}
         self.pending = {256: [], 128: []}        # tile -> [(desc tuple without item_begin, items, keepalive)]
         self.items = {256: 0, 128: 0}
         self.small = []                          # descriptors for the register-staged kernel (small / fp32-operand problems)
@@ -228,6 +231,12 @@ class WgradQueue:
         self.enabled = True
         self.written = set()                     # data_ptr of gradient buffers that received a contribution this step
         self.stores = {}                         # data_ptr -> store flag of a queued, not yet launched "store" descriptor
+
+    def overlap_exchange(self):
+        """Data parallel: launch smaller groups (about 4 waves of workgroups), so that the backbone's weight gradients become final
+        -- and their buckets' all-reduce starts -- stage by stage instead of in one group at the end of the backward pass."""
+        if not os.environ.get("UENC_WGRAD_FLUSH"):
+            self.FLUSH_ITEMS = {256: 1024, 128: 4096}
 
     @staticmethod
     def eligible(dy, x, gw) -> bool:
