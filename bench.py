@@ -267,6 +267,8 @@ def main():
     torch.manual_seed(0)                       # identical replicas (GradBuckets also broadcasts rank 0's parameters)
     model = build_model(make_cfg(device))
     model.eval()                               # deterministic path: dropout / stochastic depth = identity (the full FLOPs)
+    if os.environ.get("UENC_BENCH_TRAIN") == "1":        # profiling aid: the timed steps themselves in training mode (workload string says so)
+        model.train()
     buckets = GradBuckets(model, bucket_mb=args.bucket_mb)
 
     def make_batch(r):
@@ -404,7 +406,7 @@ def main():
                                     "150-query masked-attention decoder), 1024x2048, fwd+bwd, synthetic loss") if swin else
                                    ("BASELINE configs[4]: full OneFormer with the DiNAT-L backbone (neighbourhood attention, kernel 7), "
                                     "1024x2048, fwd+bwd, synthetic loss [UENC_BENCH_BACKBONE=dinat]"),
-                       "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}", "mode": "eval() (train_mode reported separately)"},
+                       "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}", "mode": "train()" if os.environ.get("UENC_BENCH_TRAIN") == "1" else "eval() (train_mode reported separately)"},
             "step_ms": {"median": round(statistics.median(step_ms), 3), "min": round(min(step_ms), 3), "max": round(max(step_ms), 3)},
             "host_enqueue_ms": round(host_ms, 2),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s",

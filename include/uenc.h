@@ -112,6 +112,12 @@ int uenc_col2im3x3_s2(const void* dcol, float* dx, int B, int H, int W, int C, v
 int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                  int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                  void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, void* stream);
+/* The same with alpha multiplied per SAMPLE: row m uses alpha * sample_scale[m / rows_per_sample] (sample_scale: device fp32).
+ * Stochastic depth as an epilogue -- timm DropPath(x) = x * floor(keep + U) / keep per image (reference backbone/swin.py:8, 279, 289):
+ * the residual-branch GEMM runs over all images at once, a dropped image's rows come out as the residual alone.  Stored results only. */
+int uenc_gemm_nt_scaled(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
+                        int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
+                        void* aux_out, long ldaux_out, float alpha, const float* sample_scale, int rows_per_sample, void* stream);
 /* Split-K with STORED partial sums (no atomics): split s of `splitk` writes its fp32 partial product to P + s * part_stride
  * (row stride ldp); the caller sums the slices.  splitk must equal uenc_gemm_nt_splits(K, requested) (the number of non-empty
  * k-ranges after rounding to 64).  Replaces the reference's torch.einsum("bqc,bchw->bqhw") backward w.r.t. the mask embedding
@@ -131,17 +137,22 @@ int uenc_gemm_nt_batched(const void* A, int a_dtype, long lda, long bsA, const v
  * mm / sum backward of every Linear above. */
 int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
                  float* db, int M, int N, int K, int splitm, void* stream);
+/* dW += alpha * dY^T X, db += alpha * column sums: the weight gradient of a residual branch whose output was scaled by alpha
+ * (stochastic depth, timm DropPath at reference backbone/swin.py:279, 289; the branch's dropped images are left out of M). */
+int uenc_gemm_tn_scaled(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
+                        float* db, int M, int N, int K, int splitm, float alpha, void* stream);
 
 /* Grouped weight gradients: one launch for many (dY, X, dW, db) problems of the form above (bf16 operands only).
- * table: n descriptors in DEVICE memory, 88 bytes each:
- *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, tiles_k, mlen, nsplit, item_begin, store; }
+ * table: n descriptors in DEVICE memory, 96 bytes each:
+ *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, tiles_k, mlen, nsplit, item_begin, store; float alpha; int zero; }
+ * alpha multiplies the problem's sums (0 is read as 1).
  * M % 64 == 0; mlen (tokens per split, % 64 == 0) * nsplit >= M; tiles_k = ceil(K / tile); item_begin = exclusive prefix
  * sum of ceil(N / tile) * tiles_k * nsplit; total_items = the full sum.  tile = 256 or 128.  Accumulates into dW / db
  * (atomic adds), or, for a descriptor with store != 0 and nsplit == 1, overwrites them with plain stores.
  * flops = 2 * sum(M N K), used by uenc_prof_* only. */
 int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, void* stream);
 /* The same for the register-staged kernel (any M, fp32|bf16 operands, 128 x 128 tiles): descriptors of 96 bytes
- *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin, 0; }
+ *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin; float alpha; }   (alpha: as above)
  * tiles_k = ceil(K / 128), mlen % 64 == 0, item_begin = exclusive prefix sum of ceil(N / 128) * tiles_k * nsplit. */
 int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double flops, void* stream);
 

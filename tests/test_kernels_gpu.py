@@ -414,3 +414,45 @@ def test_gemm_nt_splitk_stored_partials(K, M, N, Kd, split):
     got = K.gemm_nt_splitk(a, w, split)
     want = a.float() @ w.float().t()
     assert float((got - want).norm() / want.norm()) < 1e-3       # fp32 accumulation of exact bf16 products: order only
+
+
+@pytest.mark.parametrize("M,N,K_,nsamp", [(300, 192, 64, 3), (2048, 256, 128, 2), (49152, 768, 256, 3), (16384, 3072, 256, 2)])
+def test_gemm_nt_per_sample_scale(K, M, N, K_, nsamp):
+    """uenc_gemm_nt_scaled: alpha multiplied per sample (stochastic depth in the epilogue), on the small, the 128-tile and the 256-tile
+    kernels (stored fp32 residual form through the LDS-staged epilogue, bf16 activation-derivative form through the direct one)."""
+    L = M // nsamp
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias, res = _r(N, seed=3), _r(M, N, seed=4)
+    sc = torch.tensor([1.25, 0.0, 2.0][:nsamp], device="cuda")
+    rows = sc.repeat_interleave(L)[:, None]
+    lin = a.float() @ w.float().t() + bias
+    got = K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=torch.float32, sample_scale=sc, rows_per_sample=L)
+    _close(got, res + rows * lin, 3e-3, 2e-3)
+    assert torch.equal(got[L:2 * L], res[L:2 * L])                 # the dropped sample's rows are the residual, bit for bit
+    pre = _r(M, N, seed=5, dtype=torch.bfloat16)
+    got2 = K.gemm_nt(a, w, epilogue=K.EPI_MUL_DRELU, aux=pre, sample_scale=sc, rows_per_sample=L)
+    _close(got2, rows * (a.float() @ w.float().t()) * (pre.float() > 0), 3e-2, 2e-2)
+    got3 = K.gemm_nt(a, w, bias=bias, alpha=0.5, sample_scale=sc, rows_per_sample=L, out_dtype=torch.float32)
+    _close(got3, 0.5 * rows * lin, 3e-3, 2e-3)
+
+
+@pytest.mark.parametrize("M,N,K_", [(4096, 256, 256), (16384, 768, 256), (320, 64, 72)])
+def test_weight_gradient_alpha(K, M, N, K_):
+    """alpha of the weight-gradient GEMMs (uenc_gemm_tn_scaled and the `alpha` field of the grouped descriptors): the deferred group,
+    the small group and the direct launch."""
+    from uenc import ops
+    dy = _r(M, N, seed=1, dtype=torch.bfloat16)
+    x = _r(M, K_, seed=2, dtype=torch.bfloat16)
+    want_w = 1.5 * (dy.float().t() @ x.float())
+    want_b = 1.5 * dy.float().sum(0)
+    gw, gb = torch.zeros(N, K_, device="cuda"), torch.zeros(N, device="cuda")
+    K.gemm_tn(dy, x, gw, gb, alpha=1.5)
+    _close(gw, want_w, 2e-3 * float(want_w.abs().max()), 2e-3); _close(gb, want_b, 2e-3 * float(want_b.abs().max()), 2e-3)
+    gw2, gb2 = torch.zeros(N, K_, device="cuda"), torch.zeros(N, device="cuda")
+    ops._tn(dy, x, gw2, gb2, alpha=1.5)
+    ops._tn(dy[: M // 2], x[: M // 2], gw2, gb2, alpha=-1.5)       # a row range, negative alpha: the first half cancels
+    ops.flush_wgrads()
+    want2 = 1.5 * (dy[M // 2:].float().t() @ x[M // 2:].float())
+    _close(gw2, want2, 3e-3 * float(want2.abs().max()), 3e-3)
+    _close(gb2, 1.5 * dy[M // 2:].float().sum(0), 3e-3 * float(want_b.abs().max()), 3e-3)

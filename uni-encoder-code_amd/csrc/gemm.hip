@@ -41,10 +41,16 @@ struct GemmNT {
     int variant;   // debug A/B switch
     int persist;   // gemm_nt256_kernel: the grid is smaller than the tile count, workgroups walk tile positions
     float alpha;
+    const float* sample_scale; float inv_rows;   // optional per-sample multiplier of alpha: row m belongs to sample floor(m / rows_per_sample)
     long part_stride;     // > 0: split-K with STORED partials: split y writes its tile to C + y * part_stride (fp32 elements), no atomics
     int splits;           // gridDim.y
     long bsA, bsW, bsC;   // batched form (gemm_nt_kernel only): element strides between the problems of blockIdx.z
 };
+
+// alpha of output row m: p.alpha, times the row's sample scale when one is given (DropPath: 0 or 1 / keep_prob per image)
+__device__ __forceinline__ float nt_alpha(const GemmNT& p, int m) {
+    return p.sample_scale == nullptr ? p.alpha : p.alpha * p.sample_scale[(int)(((float)m + 0.5f) * p.inv_rows)];
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -195,8 +201,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmNT p) {
             if (m >= p.M) continue;
             const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
             float v[8];
+            const float al = nt_alpha(p, m);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * p.alpha; v[4 + r] = (a1[r] + bv[4 + r]) * p.alpha; }
+            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * al; v[4 + r] = (a1[r] + bv[4 + r]) * al; }
             if (EPI == EPI_GELU) {
                 if (p.aux_out != nullptr) {
                     bf16x8 pre;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNT p) {
             if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+        for (int r = 0; r < 8; ++r) v[r] *= nt_alpha(p, m);
         epilogue8<EPI, OUT_F32>(p, m, n, full8, v);
     }
 }
@@ -672,10 +679,11 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             const int m = mrow + j * 16;
             const bool row_ok = m < p.M;
             float v[4][4];
+            const float al = nt_alpha(p, min(m, p.M - 1));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] = (acc[i][j][r] + bv4[i][r]) * p.alpha;
+                for (int r = 0; r < 4; ++r) v[i][r] = (acc[i][j][r] + bv4[i][r]) * al;
             u32x2 pre2[4];
             if (EPI == EPI_GELU) {
 #pragma unroll
@@ -779,8 +787,9 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             if (m >= p.M) continue;
             const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
             float v[8];
+            const float al = nt_alpha(p, m);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * p.alpha; v[4 + r] = (a1[r] + bv[4 + r]) * p.alpha; }
+            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * al; v[4 + r] = (a1[r] + bv[4 + r]) * al; }
             if (skip_stores) {
                 if (EPI == EPI_GELU) {
 #pragma unroll
@@ -873,7 +882,7 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
 static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                         int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                         void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, int batch, long bsA, long bsW,
-                        long bsC, hipStream_t stream, long part_stride = 0) {
+                        long bsC, hipStream_t stream, long part_stride = 0, const float* sample_scale = nullptr, int rows_per_sample = 0) {
     UENC_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0);
     UENC_CHECK_ARG(a_dtype == UENC_F32 || a_dtype == UENC_BF16);
     UENC_CHECK_ARG(c_dtype == UENC_F32 || c_dtype == UENC_BF16);
@@ -904,6 +913,11 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         p.atomic = 0; p.part_stride = part_stride;
     }
     p.alpha = alpha;
+    p.sample_scale = nullptr; p.inv_rows = 0.f;
+    if (sample_scale != nullptr) {        // per-sample multiplier of alpha (stored results only)
+        UENC_CHECK_ARG(rows_per_sample > 0 && !p.atomic && !partials && batch == 1 && M < (1 << 22));
+        p.sample_scale = sample_scale; p.inv_rows = 1.0f / (float)rows_per_sample;
+    }
     p.bsA = bsA; p.bsW = bsW; p.bsC = bsC;
     dim3 grid(p.tiles_m * p.tiles_n, splitk, batch), block(GEMM_THREADS);
     const bool prof = uenc_prof_on();
@@ -1006,6 +1020,18 @@ extern "C" int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W,
                         accumulate, 1, 0, 0, 0, stream);
 }
 
+// uenc_gemm_nt with alpha multiplied per SAMPLE: C[m][n] = epi(alpha * sample_scale[m / rows_per_sample] * (A W^T + bias)[m][n]).
+// sample_scale: device pointer to ceil(M / rows_per_sample) floats.  Stochastic depth (timm DropPath, reference backbone/swin.py:279,
+// 289) as an epilogue: a residual branch of image b is scaled by 0 or 1 / keep_prob while the GEMM runs over all images at once.
+extern "C" int uenc_gemm_nt_scaled(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
+                                   int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
+                                   void* aux_out, long ldaux_out, float alpha, const float* sample_scale, int rows_per_sample,
+                                   hipStream_t stream) {
+    UENC_CHECK_ARG(sample_scale != nullptr && rows_per_sample > 0);
+    return gemm_nt_impl(A, a_dtype, lda, W, ldw, C, c_dtype, ldc, M, N, K, bias, epilogue, aux, ldaux, aux_out, ldaux_out, alpha, 1,
+                        0, 1, 0, 0, 0, stream, 0, sample_scale, rows_per_sample);
+}
+
 // Split-K with stored partial sums: split s (of `splitk`) writes sum over its k-range to P + s * part_stride (fp32, ldp); the
 // caller sums the `splitk` slices.  For long contractions with few output tiles (d(mask embeddings): 1536 x 256 outputs over
 // 131072 pixels): fp32 atomics are per-lane 64-byte memory-side transactions, ~10 us per split here; stored tiles are ~1.
@@ -1056,6 +1082,7 @@ struct GemmTN {
     int mlen;  // tokens per split (multiple of BK)
     int store; // tnbig only: 1 = the tile is stored (dW = ..., db = ...: single split, no prior zeroing), 0 = added atomically
     int variant;   // debug A/B switch (UENC_GEMM_VARIANT)
+    float alpha;   // multiplies the sums (dW, db) before they are stored / added
 };
 
 __device__ __forceinline__ void transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
@@ -1158,7 +1185,7 @@ __device__ __forceinline__ void tn_small_body(const GemmTN& p, int tile, int msp
             float v = bsum[c];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
             const int n = n0 + cb * 8 + c;
-            if (mb == 0 && n < p.N) atomicAdd(p.db + n, v);
+            if (mb == 0 && n < p.N) atomicAdd(p.db + n, v * p.alpha);
         }
     }
 
@@ -1184,8 +1211,8 @@ __device__ __forceinline__ void tn_small_body(const GemmTN& p, int tile, int msp
             for (int q = 0; q < 2; ++q) {
                 const int k = k0 + lane + 64 * q;
                 if (k < p.K) {
-                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
-                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q] * p.alpha;
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q] * p.alpha);
                 }
             }
         }
@@ -1201,7 +1228,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmTN p) {
 struct TnSmallDesc {
     const void* dY; const void* X; float* dW; float* db;
     long ldy, ldx, ldw;
-    int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin, pad_;
+    int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin;
+    float alpha;              // multiplies the sums; 0 is read as 1 (descriptors written before the field existed)
 };
 
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_grouped_small_kernel(const TnSmallDesc* __restrict__ table, int n) {
@@ -1215,13 +1243,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_grouped_small_kernel(con
     GemmTN p;
     p.dY = d.dY; p.dy_f32 = d.dy_f32; p.ldy = d.ldy; p.X = d.X; p.x_f32 = d.x_f32; p.ldx = d.ldx;
     p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = 0;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = 0; p.alpha = d.alpha == 0.f ? 1.f : d.alpha;
     const int local = item - d.item_begin;
     tn_small_body(p, local / d.nsplit, local % d.nsplit);
 }
 
 // table: n descriptors (device memory) of 96 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit,
-// item_begin, 0}: row-major dY [M][N] / X [M][K], fp32 (ld % 4 == 0) or bf16 (ld % 8 == 0), 16-byte aligned, N % 8 == 0,
+// item_begin, alpha (float; 0 = 1)}: row-major dY [M][N] / X [M][K], fp32 (ld % 4 == 0) or bf16 (ld % 8 == 0), 16-byte aligned, N % 8 == 0,
 // K % 8 == 0; tiles_k = ceil(K / 128); mlen (tokens per split) % 64 == 0; descriptor i owns items
 // [item_begin, item_begin + ceil(N / 128) * tiles_k * nsplit).  dW[n][k] += sum_m dY[m][n] X[m][k]; db[n] += sum_m dY[m][n].
 extern "C" int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double flops, hipStream_t stream) {
@@ -1356,7 +1384,7 @@ __device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit
             float v = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
-            if (n0 + t < p.N) { if (p.store == 1) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
+            if (n0 + t < p.N) { if (p.store == 1) p.db[n0 + t] = v * p.alpha; else atomicAdd(p.db + n0 + t, v * p.alpha); }
         }
     }
     // acc[i][j][r] = dW[n = n0 + wn*64 + j*16 + fr][k = k0 + wk*WKT*16 + i*16 + 4*fg + r]; passes of 64 n-rows
@@ -1378,8 +1406,8 @@ __device__ __forceinline__ void tnbig_body(const GemmTN& p, int tile, int msplit
             for (int q = 0; q < TILE / 64; ++q) {
                 const int k = k0 + lane + 64 * q;
                 if (k < p.K) {
-                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
-                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q] * p.alpha;
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q] * p.alpha);
                 }
             }
         }
@@ -1485,7 +1513,7 @@ __device__ __forceinline__ void tnbig_body_deep(const GemmTN& p, int tile, int m
             float v = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) v += T[g * TILE + t];
-            if (n0 + t < p.N) { if (p.store == 1) p.db[n0 + t] = v; else atomicAdd(p.db + n0 + t, v); }
+            if (n0 + t < p.N) { if (p.store == 1) p.db[n0 + t] = v * p.alpha; else atomicAdd(p.db + n0 + t, v * p.alpha); }
         }
     }
     const int fr = lane & 15, fg = lane >> 4;
@@ -1506,8 +1534,8 @@ __device__ __forceinline__ void tnbig_body_deep(const GemmTN& p, int tile, int m
             for (int q = 0; q < TILE / 64; ++q) {
                 const int k = k0 + lane + 64 * q;
                 if (k < p.K) {
-                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
-                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q] * p.alpha;
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q] * p.alpha);
                 }
             }
         }
@@ -1629,7 +1657,7 @@ __device__ __forceinline__ void tnbig_body_asm(const GemmTN& p, int tile, int ms
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + fr;
-            if (n < p.N) { if (p.store == 1) p.db[n] = accb[j][0]; else atomicAdd(p.db + n, accb[j][0]); }
+            if (n < p.N) { if (p.store == 1) p.db[n] = accb[j][0] * p.alpha; else atomicAdd(p.db + n, accb[j][0] * p.alpha); }
         }
     }
 #pragma unroll
@@ -1649,8 +1677,8 @@ __device__ __forceinline__ void tnbig_body_asm(const GemmTN& p, int tile, int ms
             for (int q = 0; q < TILE / 64; ++q) {
                 const int k = k0 + lane + 64 * q;
                 if (k < p.K) {
-                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q];
-                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q]);
+                    if (p.store) p.dW[(long)n * p.ldw + k] = T[row * LDT + lane + 64 * q] * p.alpha;
+                    else atomicAdd(p.dW + (long)n * p.ldw + k, T[row * LDT + lane + 64 * q] * p.alpha);
                 }
             }
         }
@@ -1675,6 +1703,7 @@ struct TnGroupDesc {
     long ldy, ldx, ldw;
     int M, N, K, tiles_k;
     int mlen, nsplit, item_begin, store;
+    float alpha; int pad_;    // alpha multiplies the sums; 0 is read as 1
 };
 
 // Item order (XCD_WINDOWS): what shares operand panels must run on ONE XCD at the same time, or every tile re-fetches its
@@ -1701,7 +1730,7 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
     GemmTN p;
     p.dY = d.dY; p.dy_f32 = 0; p.ldy = d.ldy; p.X = d.X; p.x_f32 = 0; p.ldx = d.ldx;
     p.dW = d.dW; p.ldw = d.ldw; p.db = d.db; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.nsplit == 1 ? d.store : 0; p.variant = 0;
+    p.tiles_n = 0; p.tiles_k = d.tiles_k; p.mlen = d.mlen; p.store = d.nsplit == 1 ? d.store : 0; p.variant = 0; p.alpha = d.alpha == 0.f ? 1.f : d.alpha;
     const int local = item - d.item_begin;
     int tile, msplit;
     if (XCD_WINDOWS) {
@@ -1715,14 +1744,14 @@ __global__ __launch_bounds__(TILE * 2) void gemm_tnbig_grouped_kernel(const TnGr
     else tnbig_body<TILE>(p, tile, msplit);
 }
 
-// table: n descriptors (device memory) of 88 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, item_begin, store}:
+// table: n descriptors (device memory) of 96 bytes {dY, X, dW, db, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, item_begin, store, alpha (float; 0 = 1), 0}:
 // bf16 row-major operands dY [M][N] / X [M][K] (16-byte aligned, ld % 8 == 0), M % 64 == 0, mlen % 64 == 0,
 // tiles_k = ceil(K / tile); descriptor i owns items [item_begin, item_begin + ceil(N/tile) * tiles_k * nsplit).
 // dW[n][k] += sum_m dY[m][n] X[m][k], db[n] += sum_m dY[m][n] (db may be NULL); store != 0 (needs nsplit == 1): "=" instead
 // of "+=" with plain stores; store == 2: dW is stored, db still added (a bias gradient that also receives other contributions).  tile = 256 or 128.
 extern "C" int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, hipStream_t stream) {
     UENC_CHECK_ARG(table && n > 0 && total_items > 0 && (tile == 256 || tile == 128) && ((uintptr_t)table & 7) == 0);
-    static_assert(sizeof(TnGroupDesc) == 88, "descriptor layout is part of the ABI");
+    static_assert(sizeof(TnGroupDesc) == 96, "descriptor layout is part of the ABI");
     static bool attr_set = false;
     if (!attr_set) {
         const void* fns[4] = {(const void*)gemm_tnbig_grouped_kernel<256, true>, (const void*)gemm_tnbig_grouped_kernel<256, false>,
@@ -1776,8 +1805,8 @@ static int launch_tnbig(GemmTN& p, int M, int N, int K, int splitm, int max_spli
     return UENC_OK;
 }
 
-extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
-                            float* db, int M, int N, int K, int splitm, hipStream_t stream) {
+static int gemm_tn_impl(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
+                        float* db, int M, int N, int K, int splitm, float alpha, hipStream_t stream) {
     UENC_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0);
     UENC_CHECK_ARG(N % 8 == 0 && K % 8 == 0);
     UENC_CHECK_ARG(dy_dtype == UENC_F32 ? (ldy % 4 == 0) : (dy_dtype == UENC_BF16 && ldy % 8 == 0));
@@ -1785,7 +1814,7 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     UENC_CHECK_ARG(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0);
     GemmTN p;
     p.dY = dY; p.dy_f32 = (dy_dtype == UENC_F32); p.ldy = ldy; p.X = X; p.x_f32 = (x_dtype == UENC_F32); p.ldx = ldx;
-    p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K; p.store = 0;
+    p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K; p.store = 0; p.alpha = alpha;
     { const char* e0 = getenv("UENC_GEMM_VARIANT"); p.variant = e0 ? atoi(e0) : 0; }
     // LDS-DMA paths: bf16 operands, whole 64-token stages.  256x256 tiles when the output has >= 20 of them (every split
     // of the token range costs a 256 KB atomic burst per tile, so splits are capped at 8); else 128x128 tiles, whose
@@ -1818,4 +1847,15 @@ extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* 
     hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, p);
     if (prof) uenc_prof_end(stream);
     UENC_LAUNCH_RET();
+}
+
+extern "C" int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
+                            float* db, int M, int N, int K, int splitm, hipStream_t stream) {
+    return gemm_tn_impl(dY, dy_dtype, ldy, X, x_dtype, ldx, dW, ldw, db, M, N, K, splitm, 1.0f, stream);
+}
+
+// dW += alpha * dY^T X, db += alpha * column sums of dY (the weight gradient of a branch whose output was scaled by alpha: DropPath)
+extern "C" int uenc_gemm_tn_scaled(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
+                                   float* db, int M, int N, int K, int splitm, float alpha, hipStream_t stream) {
+    return gemm_tn_impl(dY, dy_dtype, ldy, X, x_dtype, ldx, dW, ldw, db, M, N, K, splitm, alpha, stream);
 }

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "uenc_upsample_bilinear": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_attn_mask": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_nt": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_i, c_p],
+    "uenc_gemm_nt_scaled": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p],
     "uenc_groupnorm_tokens_scratch_bytes": [c_i, c_i, c_i, c_i],
     "uenc_groupnorm_tokens_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "uenc_groupnorm_tokens_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -44,6 +45,7 @@ _SIGNATURES = {
     "uenc_gemm_nt_partials": [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
     "uenc_gemm_nt_batched": [c_p, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p],
     "uenc_gemm_tn": [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
+    "uenc_gemm_tn_scaled": [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_gemm_tn_grouped": [c_p, c_i, c_i, c_i, ctypes.c_double, c_p],
     "uenc_gemm_tn_grouped_small": [c_p, c_i, c_i, ctypes.c_double, c_p],
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p, c_p],

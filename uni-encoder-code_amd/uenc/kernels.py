@@ -69,12 +69,15 @@ def cast_transpose_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
             aux: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
             out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, alpha: float = 1.0,
-            splitk: int = 1, accumulate: bool = False) -> torch.Tensor:
-    """out[m, n] = epi(alpha * sum_k a[m, k] * w[n, k] + bias[n]).  a fp32|bf16, w bf16, fp32 accumulate."""
+            splitk: int = 1, accumulate: bool = False, sample_scale: Optional[torch.Tensor] = None, rows_per_sample: int = 0) -> torch.Tensor:
+    """out[m, n] = epi(alpha * (sum_k a[m, k] * w[n, k] + bias[n])).  a fp32|bf16, w bf16, fp32 accumulate.
+    sample_scale (device fp32, one entry per `rows_per_sample` rows): alpha is multiplied by the row's sample scale (DropPath)."""
     _mat(a, "a"); _mat(w, "w")
     M, K = a.shape
     N, K2 = w.shape
     if EXACT:
+        if sample_scale is not None:
+            raise capi.UencError("gemm_nt: the fp32 verification kernels take no per-sample scale")
         return _gemm_nt_exact(a, w, bias, epilogue, aux, aux_out, out, alpha, accumulate)
     if K != K2 or w.dtype != torch.bfloat16:
         raise capi.UencError(f"gemm_nt: a {tuple(a.shape)} vs w {tuple(w.shape)} / {w.dtype}")
@@ -91,6 +94,14 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = 
         assert aux.dtype == (torch.float32 if epilogue == EPI_RESIDUAL else torch.bfloat16)
     if aux_out is not None:
         _mat(aux_out, "aux_out"); assert aux_out.shape == (M, N) and aux_out.dtype == torch.bfloat16
+    if sample_scale is not None:
+        assert sample_scale.dtype == torch.float32 and sample_scale.is_cuda and sample_scale.is_contiguous()
+        assert rows_per_sample > 0 and sample_scale.numel() * rows_per_sample >= M and splitk == 1 and not accumulate
+        check(lib.uenc_gemm_nt_scaled(a.data_ptr(), dt(a), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), dt(out),
+                                      out.stride(0), M, N, K, ptr(bias), epilogue, ptr(aux), aux.stride(0) if aux is not None else 0,
+                                      ptr(aux_out), aux_out.stride(0) if aux_out is not None else 0, float(alpha), sample_scale.data_ptr(),
+                                      int(rows_per_sample), stream_ptr()), "gemm_nt_scaled")
+        return out
     check(lib.uenc_gemm_nt(a.data_ptr(), dt(a), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), dt(out),
                            out.stride(0), M, N, K, ptr(bias), epilogue, ptr(aux), aux.stride(0) if aux is not None else 0,
                            ptr(aux_out), aux_out.stride(0) if aux_out is not None else 0, float(alpha), int(splitk),
@@ -154,8 +165,8 @@ def gemm_nt_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, alph
     return out
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, splitm: int = 0):
-    """dw[n, k] += sum_m dy[m, n] * x[m, k];  db[n] += sum_m dy[m, n].  dy bf16, x fp32|bf16, dw/db fp32 (accumulated)."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, splitm: int = 0, alpha: float = 1.0):
+    """dw[n, k] += alpha * sum_m dy[m, n] * x[m, k];  db[n] += alpha * sum_m dy[m, n].  dy bf16, x fp32|bf16, dw/db fp32 (accumulated)."""
     _mat(dy, "dy"); _mat(x, "x"); _mat(dw, "dw")
     M, N = dy.shape
     M2, K = x.shape
@@ -164,9 +175,13 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[to
     if db is not None:
         assert db.dtype == torch.float32 and db.numel() == N and db.is_contiguous()
     if EXACT:
-        assert dy.dtype == torch.float32 and x.dtype == torch.float32
+        assert dy.dtype == torch.float32 and x.dtype == torch.float32 and alpha == 1.0
         check(lib.uenc_gemm_tn_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), ptr(db), M, N, K,
                                    stream_ptr()), "gemm_tn_f32")
+        return
+    if alpha != 1.0:
+        check(lib.uenc_gemm_tn_scaled(dy.data_ptr(), dt(dy), dy.stride(0), x.data_ptr(), dt(x), x.stride(0), dw.data_ptr(), dw.stride(0),
+                                      ptr(db), M, N, K, int(splitm), float(alpha), stream_ptr()), "gemm_tn_scaled")
         return
     check(lib.uenc_gemm_tn(dy.data_ptr(), dt(dy), dy.stride(0), x.data_ptr(), dt(x), x.stride(0), dw.data_ptr(), dw.stride(0),
                            ptr(db), M, N, K, int(splitm), stream_ptr()), "gemm_tn")

@@ -203,10 +203,10 @@ class WgradQueue:
     """
     _DESC = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
              ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("tiles_k", "<i4"), ("mlen", "<i4"), ("nsplit", "<i4"),
-             ("item_begin", "<i4"), ("store", "<i4")]
+             ("item_begin", "<i4"), ("store", "<i4"), ("alpha", "<f4"), ("pad", "<i4")]
     _DESC_SMALL = [("dy", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("ldy", "<i8"), ("ldx", "<i8"), ("ldw", "<i8"),
                    ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("dy_f32", "<i4"), ("x_f32", "<i4"), ("tiles_k", "<i4"),
-                   ("mlen", "<i4"), ("nsplit", "<i4"), ("item_begin", "<i4"), ("pad", "<i4")]
+                   ("mlen", "<i4"), ("nsplit", "<i4"), ("item_begin", "<i4"), ("alpha", "<f4")]
     # measured on the Swin-L problem sets (tools/wgrad_group_bench.py): many short items beat few long ones (balance, more loads in
     # flight) until the per-item atomic burst shows, around 4k-8k tokens
     # `fresh` (set by begin_step): every gradient buffer is known to be zero at the start of this step, so the FIRST weight gradient
@@ -254,7 +254,7 @@ class WgradQueue:
         return (ok(dy) and ok(x) and x.shape[0] == dy.shape[0] and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
                 and gw.dtype == F32 and gw.stride(1) == 1 and gw.shape == (dy.shape[1], x.shape[1]))
 
-    def add_small(self, dy, x, gw, gb, notify=()):
+    def add_small(self, dy, x, gw, gb, notify=(), alpha: float = 1.0):
         """Queue a problem for the grouped register-staged kernel (launched with the others at flush time)."""
         M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
         mt = -(-M // 64)
@@ -265,7 +265,7 @@ class WgradQueue:
         items = -(-N // 128) * tiles_k * nsplit
         self.small.append(((dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else 0,
                             dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, int(dy.dtype == F32), int(x.dtype == F32), tiles_k, mlen,
-                            nsplit), items, (dy, x, gw, gb)))
+                            nsplit), items, (dy, x, gw, gb), float(alpha)))
         self.small_items += items
         self.notify.extend(p for p in notify if p is not None)
         self._arm()
@@ -283,7 +283,7 @@ class WgradQueue:
     def busy(self) -> bool:
         return bool(self.notify or self.items[256] or self.items[128] or self.small_items)
 
-    def add(self, dy, x, gw, gb, notify=(), first=False):
+    def add(self, dy, x, gw, gb, notify=(), first=False, alpha: float = 1.0):
         M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
         # 256 x 256 tiles re-read the operands half as often as 128 x 128 ones; they win unless padding N, K up to 256 wastes too much
         pad = lambda t: (-(-N // t) * t) * (-(-Kd // t) * t)
@@ -297,7 +297,8 @@ class WgradQueue:
         if store[0]:
             self.stores[gw.data_ptr()] = store
         self.pending[tile].append(((dy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else 0,
-                                    dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, tiles_k, mlen, nsplit), items, (dy, x, gw, gb), store))
+                                    dy.stride(0), x.stride(0), gw.stride(0), M, N, Kd, tiles_k, mlen, nsplit), items, (dy, x, gw, gb), store,
+                                   float(alpha)))
         self.items[tile] += items
         self.notify.extend(p for p in notify if p is not None)
         self._arm()
@@ -306,13 +307,13 @@ class WgradQueue:
 
     @classmethod
     def launch(cls, tile: int, descs, device):
-        """descs: [(dy_ptr, x_ptr, dw_ptr, db_ptr, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, items, store)]."""
+        """descs: [(dy_ptr, x_ptr, dw_ptr, db_ptr, ldy, ldx, ldw, M, N, K, tiles_k, mlen, nsplit, items, store[, alpha])]."""
         import numpy as np
         from .capi import check, lib, stream_ptr
         desc = np.zeros(len(descs), dtype=cls._DESC)
         begin, flops, nbytes = 0, 0.0, 0.0
         for i, d in enumerate(descs):
-            desc[i] = d[:13] + (begin, d[14])
+            desc[i] = d[:13] + (begin, d[14], d[15] if len(d) > 15 else 1.0, 0)
             begin += d[13]
             flops += 2.0 * d[7] * d[8] * d[9]
             nbytes += 2.0 * d[7] * (d[8] + d[9]) + 4.0 * d[8] * d[9]           # bf16 operands read once + the fp32 gradient written once
@@ -355,7 +356,7 @@ class WgradQueue:
             if not ent:
                 continue
             ent.sort(key=lambda e: -e[0][11])                       # longest token ranges first
-            self.launch(tile, [d + (items, st[0]) for d, items, _, st in ent], ent[0][2][0].device)
+            self.launch(tile, [d + (items, st[0], al) for d, items, _, st, al in ent], ent[0][2][0].device)
             self.pending[tile] = []
             self.items[tile] = 0
         if self.small:
@@ -363,8 +364,8 @@ class WgradQueue:
             from .capi import check, lib, stream_ptr
             desc = np.zeros(len(self.small), dtype=self._DESC_SMALL)
             begin, flops = 0, 0.0
-            for i, (d, items, _) in enumerate(self.small):
-                desc[i] = d + (begin, 0)
+            for i, (d, items, _, al) in enumerate(self.small):
+                desc[i] = d + (begin, al)
                 begin += items
                 flops += 2.0 * d[7] * d[8] * d[9]
             dev = self.small[0][2][0].device
@@ -402,16 +403,16 @@ def _tn_notify(*params):
         _notify(*params)
 
 
-def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor], notify=()):
-    """gw += dy^T x, gb += column sums of dy: deferred to a grouped launch when the operands allow it."""
+def _tn(dy: torch.Tensor, x: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor], notify=(), alpha: float = 1.0):
+    """gw += alpha * dy^T x, gb += alpha * column sums of dy: deferred to a grouped launch when the operands allow it."""
     first = WGRADS.touch(gw)
     if WGRADS.enabled and not K.EXACT and WGRADS.eligible(dy, x, gw):
-        WGRADS.add(dy, x, gw, gb, notify, first)
+        WGRADS.add(dy, x, gw, gb, notify, first, alpha)
         return
     if WGRADS.enabled and not K.EXACT and WGRADS.eligible_small(dy, x, gw):
-        WGRADS.add_small(dy, x, gw, gb, notify)
+        WGRADS.add_small(dy, x, gw, gb, notify, alpha)
         return
-    K.gemm_tn(dy, x, gw, gb)
+    K.gemm_tn(dy, x, gw, gb, alpha=alpha)
     if WGRADS.busy():
         WGRADS.notify.extend(p for p in notify if p is not None)     # keep notification order behind the queued groups
     else:
@@ -668,14 +669,33 @@ def drop_path_scales(B: int, drop_prob: float):
     return [float(v) / keep for v in torch.floor(keep + torch.rand(B)).tolist()]
 
 
+_SCALE_VECS = {}
+
+
+def _scale_vec(scales, device) -> torch.Tensor:
+    """Device copy of a tuple of per-sample DropPath multipliers; cached (a block draws from {0, 1 / keep}^B: few distinct tuples)."""
+    key = (tuple(scales), str(device))
+    t = _SCALE_VECS.get(key)
+    if t is None:
+        if len(_SCALE_VECS) > 4096:
+            _SCALE_VECS.clear()
+        t = torch.tensor(list(scales), dtype=F32, device=device)
+        _SCALE_VECS[key] = t
+    return t
+
+
 def _branch_gemm(h, w16, bias, res, out_rows, scales):
-    """out = res + scale_b * (h @ w^T + bias) per sample b (rows split evenly): the residual epilogue with alpha = scale_b."""
+    """out = res + scale_b * (h @ w^T + bias) per sample b (rows split evenly): the residual epilogue with alpha = scale_b, ONE
+    GEMM over all images (uenc_gemm_nt_scaled); a dropped image's rows come out as the residual alone."""
     M = h.shape[0]
     if scales is None:
         return K.gemm_nt(h, w16, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=F32)
-    out = torch.empty((M, out_rows), dtype=F32, device=h.device)
     B = len(scales)
     L = M // B
+    if not K.EXACT:
+        return K.gemm_nt(h, w16, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=F32, sample_scale=_scale_vec(scales, h.device),
+                         rows_per_sample=L)
+    out = torch.empty((M, out_rows), dtype=F32, device=h.device)       # fp32 verification mode: image by image
     for b, sc in enumerate(scales):
         rows = slice(b * L, (b + 1) * L)
         if sc == 0.0:
@@ -686,12 +706,52 @@ def _branch_gemm(h, w16, bias, res, out_rows, scales):
 
 
 def _scaled_rows(g16, scales):
-    """bf16 copy of a (M, C) gradient with sample b's rows multiplied by scale_b (the backward of the DropPath scaling)."""
+    """bf16 copy of a (M, C) gradient with sample b's rows multiplied by scale_b (the backward of the DropPath scaling).
+    Only the fp32 verification mode takes this path; the bf16 mode scales inside the GEMM epilogues (`_branch_dgrad`, `_branch_wgrad`)."""
     if scales is None:
         return g16
     B = len(scales)
     sc = torch.tensor(scales, dtype=torch.float32).to(g16.device, non_blocking=True)
     return (g16.view(B, -1, g16.shape[-1]).float() * sc.view(B, 1, 1)).to(K.adt()).view(g16.shape)
+
+
+def _branch_dgrad(g16, w16t, scales, **kw):
+    """(scale_b * g) @ w for a DropPath-scaled branch: the per-sample scale rides in the dgrad GEMM's epilogue (it commutes with the
+    contraction and with the activation-derivative product of `kw`)."""
+    if scales is None or K.EXACT:
+        return K.gemm_nt(g16, w16t, **kw)
+    return K.gemm_nt(g16, w16t, sample_scale=_scale_vec(scales, g16.device), rows_per_sample=g16.shape[0] // len(scales), **kw)
+
+
+def _branch_wgrad(g16, x, gw, gb, notify, scales):
+    """gw += (scale * g)^T x, gb += column sums of scale * g, for a DropPath-scaled branch and the UNSCALED gradient g16: the kept
+    images share one multiplier 1 / keep, so the sum runs over their rows only and is scaled once (alpha of the TN GEMM).  Exactly
+    one gradient-ready notification whatever was dropped (the data-parallel bucket scheduler counts contributions)."""
+    if scales is None or K.EXACT:
+        _tn(g16, x, gw, gb, notify)
+        return
+    B = len(scales)
+    L = g16.shape[0] // B
+    runs, b = [], 0
+    while b < B:                                       # maximal runs of kept images = contiguous row ranges
+        if scales[b] != 0.0:
+            e = b
+            while e + 1 < B and scales[e + 1] != 0.0:
+                e += 1
+            runs.append((b, e + 1))
+            b = e + 1
+        else:
+            b += 1
+    if not runs:
+        if WGRADS.busy():
+            WGRADS.notify.extend(p for p in notify if p is not None)
+        else:
+            _notify(*notify)
+        return
+    alpha = float(max(scales))
+    for i, (b0, b1) in enumerate(runs):
+        rows = slice(b0 * L, b1 * L)
+        _tn(g16[rows], x[rows], gw, gb, notify if i == len(runs) - 1 else (), alpha=alpha)
 
 
 class SwinBlockFn(torch.autograd.Function):
@@ -737,10 +797,12 @@ class SwinBlockFn(torch.autograd.Function):
         d2h = _twin(d2)                                     # written by the LayerNorm backward that produced this gradient
         if d2h is None:
             d2h = K.cast_bf16(d2)
-        d2h = _scaled_rows(d2h, s2)                         # DropPath: the MLP branch sees scale_b * gradient
-        dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)             # (M, 4C) d(pre-GELU)
+        if K.EXACT:
+            d2h, s2 = _scaled_rows(d2h, s2), None           # (verification mode: the scaled gradient is materialised)
+        # DropPath: the MLP branch sees scale_b * gradient -- applied in the dgrad epilogue and as the wgrad's alpha
+        dh = _branch_dgrad(d2h, CACHE.mat_t(w2), s2, epilogue=K.EPI_MUL_DGELU, aux=pre)     # (M, 4C) d(pre-GELU)
         if train:
-            _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
+            _branch_wgrad(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2), s2)
         dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))                                              # (M, C)
         if train:
             _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
@@ -748,10 +810,12 @@ class SwinBlockFn(torch.autograd.Function):
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
         # attention branch
-        dx1h = _scaled_rows(tw[0], s1)
-        dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))                                        # (M, C) bf16
+        dx1h = tw[0]
+        if K.EXACT:
+            dx1h, s1 = _scaled_rows(dx1h, s1), None
+        dattn = _branch_dgrad(dx1h, CACHE.mat_t(wproj), s1)                                # (M, C) bf16
         if train:
-            _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
+            _branch_wgrad(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj), s1)
         # (the kernels add the relative-position-table gradient and the padding-slot share of the qkv-bias gradient straight into .grad)
         dqkv = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn, dattn.view(B, H, W, C), ws, shift, scale,
                                  dtable=grad_buf(table) if train else None, dbias=grad_buf(bqkv) if train else None)
@@ -1187,20 +1251,23 @@ class NATLayerFn(torch.autograd.Function):
         d2h = _twin(d2)
         if d2h is None:
             d2h = K.cast_bf16(d2)
-        d2h = _scaled_rows(d2h, s2)
-        dh = K.gemm_nt(d2h, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DGELU, aux=pre)
+        if K.EXACT:
+            d2h, s2 = _scaled_rows(d2h, s2), None
+        dh = _branch_dgrad(d2h, CACHE.mat_t(w2), s2, epilogue=K.EPI_MUL_DGELU, aux=pre)
         if train:
-            _tn(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2))
+            _branch_wgrad(d2h, h, grad_buf(w2), grad_buf(bb2), (w2, bb2), s2)
         dxn2 = K.gemm_nt(dh, CACHE.mat_t(w1))
         if train:
             _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
         tw = []
         dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
-        dx1h = _scaled_rows(tw[0], s1)
-        dattn = K.gemm_nt(dx1h, CACHE.mat_t(wproj))
+        dx1h = tw[0]
+        if K.EXACT:
+            dx1h, s1 = _scaled_rows(dx1h, s1), None
+        dattn = _branch_dgrad(dx1h, CACHE.mat_t(wproj), s1)
         if train:
-            _tn(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj))
+            _branch_wgrad(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj), s1)
         dqkv = K.na2d_bwd(qkv.view(B, H, W, 3 * C), rp, attn, dattn.view(B, H, W, C), lse, nH, ks, dilation, scale,
                           grad_buf(rpb) if (train and rpb.requires_grad) else None)
         dqkv2 = dqkv.view(M, 3 * C)
