@@ -101,7 +101,13 @@ class _WeightedMeanSquares(torch.autograd.Function):
     def backward(ctx, g):
         xs = ctx.saved_tensors
         c = (ctx.coef * (2.0 * g)).unbind()          # one launch for the 20 coefficients
-        return (None,) + tuple(x * ci.to(x.dtype) for x, ci in zip(xs, c))
+        # multi-tensor scaled copies (one launch per dtype group); `x * c_i` with a 0-dim device tensor runs the un-vectorised broadcast kernel
+        out = [None] * len(xs)
+        for dt in {x.dtype for x in xs}:
+            idx = [i for i, x in enumerate(xs) if x.dtype == dt]
+            for i, y in zip(idx, torch._foreach_mul([xs[i] for i in idx], [c[i].to(dt) for i in idx])):
+                out[i] = y
+        return (None,) + tuple(out)
 
 
 def synthetic_loss(out):

@@ -43,41 +43,47 @@ extern "C" int uenc_cast_transpose_f32_bf16(const float* src, void* dst, int R, 
 // Bilinear resize (align_corners = False) of (NC, Hi, Wi) fp32 planes to (NC, Ho, Wo): the final x4 mask upsample of
 // reference model/oneformer_model.py:255-263 (2.5 GB of output at bs 2: pure HBM write).  Each thread produces four
 // consecutive output pixels of a row (one 16-byte store); the <= 2 x 6 input values it needs come from L1 / L2.
-__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long NC,
-                                                                int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
+// Grid (row quarters, Ho, planes): plane and output row come from the block index (the first version derived them from a flat 64-bit
+// index -- two 64-bit divisions per thread, more VALU time than the store stream leaves room for).
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int planes_per_z,
+                                                                long NC, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
+    const int oy = blockIdx.y;
+    float fy = ((float)oy + 0.5f) * sy - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = min((int)fy, Hi - 1), y1 = min(y0 + 1, Hi - 1);
+    const float ly = fy - (float)y0;
     const int wq = Wo >> 2;
-    const long total = NC * (long)Ho * wq;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int xq = (int)(idx % wq);
-        const long r = idx / wq;
-        const int oy = (int)(r % Ho);
-        const long nc = r / Ho;
-        float fy = ((float)oy + 0.5f) * sy - 0.5f;
-        fy = fy < 0.f ? 0.f : fy;
-        const int y0 = min((int)fy, Hi - 1), y1 = min(y0 + 1, Hi - 1);
-        const float ly = fy - (float)y0;
+    for (int pz = 0; pz < planes_per_z; ++pz) {
+        const long nc = (long)blockIdx.z * planes_per_z + pz;
+        if (nc >= NC) break;
         const float* r0 = in + (nc * Hi + y0) * (long)Wi;
         const float* r1 = in + (nc * Hi + y1) * (long)Wi;
-        float o[4];
+        float* orow = out + (nc * Ho + oy) * (long)Wo;
+        for (int xq = blockIdx.x * 256 + threadIdx.x; xq < wq; xq += gridDim.x * 256) {
+            float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float fx = ((float)(xq * 4 + j) + 0.5f) * sx - 0.5f;
-            fx = fx < 0.f ? 0.f : fx;
-            const int x0 = min((int)fx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
-            const float lx = fx - (float)x0;
-            const float top = r0[x0] + (r0[x1] - r0[x0]) * lx, bot = r1[x0] + (r1[x1] - r1[x0]) * lx;
-            o[j] = top + (bot - top) * ly;
+            for (int j = 0; j < 4; ++j) {
+                float fx = ((float)(xq * 4 + j) + 0.5f) * sx - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = min((int)fx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
+                const float lx = fx - (float)x0;
+                const float top = r0[x0] + (r0[x1] - r0[x0]) * lx, bot = r1[x0] + (r1[x1] - r1[x0]) * lx;
+                o[j] = top + (bot - top) * ly;
+            }
+            // streamed once, never re-read by this kernel: non-temporal stores keep the 2.5 GB out of the way of the input planes in L2
+            f32x4 v = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(v, (f32x4*)(orow + xq * 4));
         }
-        *(float4*)(out + (nc * Ho + oy) * (long)Wo + xq * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
 extern "C" int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, hipStream_t stream) {
     UENC_CHECK_ARG(in && out && NC > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Wo % 4 == 0 && ((uintptr_t)out & 15) == 0);
-    const long total = NC * (long)Ho * (Wo / 4);
-    long blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, NC, Hi, Wi, Ho, Wo,
+    UENC_CHECK_ARG(Ho <= 65535);
+    const int wq = Wo / 4;
+    const int ppz = (int)((NC + 65534) / 65535);
+    const dim3 grid((unsigned)((wq + 255) / 256 > 8 ? 8 : (wq + 255) / 256), (unsigned)Ho, (unsigned)((NC + ppz - 1) / ppz));
+    hipLaunchKernelGGL(upsample_bilinear_kernel, grid, dim3(256), 0, stream, in, out, ppz, NC, Hi, Wi, Ho, Wo,
                        (float)Hi / (float)Ho, (float)Wi / (float)Wo);
     UENC_LAUNCH_RET();
 }
