@@ -41,7 +41,13 @@ int uenc_version(void);
 const char* uenc_arch(void); /* "gfx950" */
 
 /* ---- casts: fp32 master weights -> bf16 MFMA operands (replaces autocast-style .to(bf16)) ---------- */
-int uenc_cast_f32_bf16(const float* src, void* dst, long n /* multiple of 8 */, void* stream);
+int uenc_cast_f32_bf16(const float* src, void* dst, long n /* Inverted dropout on a bf16 tensor of n elements (n % 8 == 0; in place allowed): out[i] = keep(i) ? in[i] / (1 - p) : 0 with
+ * keep(i) = hash(seed, i) >= p * 2^32 (the index hash the attention kernels use for attention-probability dropout).  The mask is a
+ * function of (seed, i): the backward calls the same entry on the gradient.  Replaces nn.Dropout between the deformable encoder
+ * layer's kernels in training mode (reference pixel_decoder/msdeformattn.py:111-119, 121-142). */
+int uenc_dropout_bf16(const void* in, void* out, long n, unsigned seed, float p, void* stream);
+
+/* multiple of 8 */, void* stream);
 int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C][R] bf16 */, int R, int C, void* stream);
 
 /* batched cast: `table` = n device-resident descriptors {const float* src; bf16* dst; int rows, cols, transpose, tiles_c;

@@ -441,12 +441,15 @@ def test_swin_block_drop_path_training(ops):
     ops.CACHE.invalidate()
 
 
-def test_deform_encoder_layer_training_dropout(ops):
-    """Training-mode dropout of the deformable encoder layer (dropout1 / 2 / 3, reference pixel_decoder/msdeformattn.py:111-142):
-    the layer run op by op with explicit keep-masks equals the oracle's layer arithmetic with the same masks, forward and backward;
-    eval mode keeps using the fused layer."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_deform_encoder_layer_training_dropout(ops, fused):
+    """Training-mode dropout of the deformable encoder layer (dropout1 / 2 / 3, reference pixel_decoder/msdeformattn.py:111-142) against
+    the oracle's layer arithmetic with the SAME keep-masks, forward and backward.  fused: the one-node layer (ops.DeformEncoderLayerFn)
+    with the index-hash masks of uenc_dropout_bf16, rebuilt on the host from the layer's seeds; not fused (no level embedding handed in):
+    the op-by-op path with explicit ATen masks.  Eval mode draws nothing."""
     import torch.nn.functional as F
     from oracle import torch_ref as T, fill
+    from uenc import kernels as Kk
     from uenc.modeling.pixel_decoder.msdeformattn import MSDeformAttnTransformerEncoderLayer, MSDeformAttnTransformerEncoder
     ops.CACHE.invalidate()
     shapes = [(6, 8), (12, 16), (24, 32)]
@@ -459,15 +462,22 @@ def test_deform_encoder_layer_training_dropout(ops):
     ss = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
     lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
     ref = MSDeformAttnTransformerEncoder.get_reference_points(shapes, torch.ones(B, 3, 2, device="cuda"), "cuda").contiguous()
+    lev = torch.zeros(3, C, device="cuda", requires_grad=True) if fused else None
     x = src.clone().requires_grad_()
     layer.train()
-    y = layer(x, pos, ref, ss, lsi)
-    m1, m2, m3 = [m.cpu() for m in layer._masks]
-    assert 0.85 < float(m1.float().mean()) < 0.95 and m2.shape == (B, S, 1024)
+    y = layer(x, pos, ref, ss, lsi, level_embed=lev)
+    if fused:
+        s1, s2, s3 = layer._seeds
+        m1 = Kk.dropout_keep_reference((B, S, C), 0.1, s1)
+        m2 = Kk.dropout_keep_reference((B, S, 1024), 0.1, s2)
+        m3 = Kk.dropout_keep_reference((B, S, C), 0.1, s3)
+    else:
+        m1, m2, m3 = [m.cpu() for m in layer._masks]
+    assert 0.85 < float(m1.float().mean()) < 0.95 and m2.shape == (B, S, 1024) and not torch.equal(m1, m3)
     dy = _r(B, S, C, seed=3)
     y.backward(dy)
     ops.flush_wgrads()
-    keep = 0.9
+    keep = 1.0 - float(torch.tensor(0.1, dtype=torch.float32))
     x2 = src.detach().cpu().requires_grad_()
     a = T.ms_deform_attn(x2 + pos.cpu(), T.encoder_reference_points(shapes), x2, shapes, sd, p + ".self_attn", 8, 4)
     h = T._ln(x2 + a * m1 / keep, sd, p + ".norm1")
@@ -482,8 +492,23 @@ def test_deform_encoder_layer_training_dropout(ops):
         cos = float(F.cosine_similarity(q.grad.cpu().flatten(), want.flatten(), dim=0))
         assert cos > 0.995 and abs(float(q.grad.norm()) / float(want.norm()) - 1) < 0.03, (name, cos)
     layer.eval()
-    assert layer(src, pos, ref, ss, lsi).shape == src.shape and len(layer._masks) == 3      # eval: no new masks drawn
+    seeds, nmask = layer._seeds, len(layer._masks)
+    assert layer(src, pos, ref, ss, lsi, level_embed=lev).shape == src.shape
+    assert layer._seeds == seeds and len(layer._masks) == nmask                               # eval: nothing new drawn
     ops.CACHE.invalidate()
+
+
+def test_dropout_bf16_kernel():
+    """uenc_dropout_bf16 against its host restatement: keep rate, scaling, in-place form, and the same mask for the same seed."""
+    from uenc import kernels as Kk
+    x = _r(3, 1000, 8, seed=5).to(torch.bfloat16)
+    y = Kk.dropout_bf16(x, 777, 0.25)
+    keep = Kk.dropout_keep_reference(x.shape, 0.25, 777)
+    want = (x.float().cpu() * keep / 0.75).to(torch.bfloat16)
+    assert torch.equal(y.cpu(), want) and 0.72 < float(keep.float().mean()) < 0.78
+    z = x.clone()
+    Kk.dropout_bf16(z, 777, 0.25, out=z)
+    assert torch.equal(z, y) and not torch.equal(Kk.dropout_bf16(x, 778, 0.25), y)
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 64), (1, 9, 13, 96), (2, 7, 10, 192), (1, 5, 5, 1536)])

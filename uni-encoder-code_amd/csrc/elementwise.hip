@@ -17,6 +17,30 @@ extern "C" int uenc_cast_f32_bf16(const float* src, void* dst, long n, hipStream
     UENC_LAUNCH_RET();
 }
 
+// Inverted dropout on a bf16 tensor: out[i] = keep(i) ? in[i] / (1 - p) : 0, keep(i) = the index hash of common.h (attn_keep) -- a pure
+// function of (seed, i), so the backward regenerates the mask instead of storing it (reference: nn.Dropout at
+// pixel_decoder/msdeformattn.py:111-142, applied between this library's GEMM / LayerNorm kernels in training mode).  In place allowed.
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, long n8, unsigned seed,
+                                                           unsigned thresh, float inv_keep) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const bf16x8 v = *(const bf16x8*)(in + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = attn_keep(seed, thresh, (unsigned long long)(i * 8 + j)) ? (bf16)((float)v[j] * inv_keep) : (bf16)0.f;
+        *(bf16x8*)(out + i * 8) = o;
+    }
+}
+
+extern "C" int uenc_dropout_bf16(const void* in, void* out, long n, unsigned seed, float p, hipStream_t stream) {
+    UENC_CHECK_ARG(in && out && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f);
+    UENC_CHECK_ARG((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dropout_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)in, (bf16*)out, n / 8, seed,
+                       attn_drop_thresh(p), 1.0f / (1.0f - p));
+    UENC_LAUNCH_RET();
+}
+
 // dst[c][r] = bf16(src[r][c]); 64x64 tiles through LDS (padded), src row-major [R][C].
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C) {
     __shared__ float tile[64][65];

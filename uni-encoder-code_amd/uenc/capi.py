@@ -41,6 +41,7 @@ _SIGNATURES = {
     "uenc_msda_prep_fwd": [c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_msda_prep_bwd": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_segment_colsum": [c_p, c_l, c_i, c_p, c_i, c_l, c_i, c_p, c_p],
+    "uenc_dropout_bf16": [c_p, c_p, c_l, c_u, c_f, c_p],
     "uenc_gemm_nt_splits": [c_i, c_i],
     "uenc_gemm_nt_partials": [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
     "uenc_gemm_nt_batched": [c_p, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p],

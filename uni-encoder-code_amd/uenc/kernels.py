@@ -38,6 +38,25 @@ def _mat(t: torch.Tensor, name: str):
     return t
 
 
+def dropout_bf16(x16: torch.Tensor, seed: int, p: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inverted dropout of a contiguous bf16 tensor with the index-hash keep mask (uenc_dropout_bf16); out=x16 for in place."""
+    assert x16.dtype == torch.bfloat16 and x16.is_contiguous() and x16.is_cuda and x16.numel() % 8 == 0
+    if out is None:
+        out = torch.empty_like(x16)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == x16.numel()
+    check(lib.uenc_dropout_bf16(x16.data_ptr(), out.data_ptr(), x16.numel(), int(seed) & 0xFFFFFFFF, float(p), stream_ptr()), "dropout_bf16")
+    return out
+
+
+def dropout_keep_reference(shape, p: float, seed: int) -> torch.Tensor:
+    """The keep-mask uenc_dropout_bf16 derives for a tensor of `shape` (row-major index), restated on the host.  Test helper."""
+    from .attention import keep_mask_reference
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return keep_mask_reference(1, 1, 1, n, p, int(seed) & 0xFFFFFFFF).view(tuple(shape))
+
+
 def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 -> bf16 copy (weights).  numel must be a multiple of 8, else falls to the padded path."""
     assert src.dtype == torch.float32 and src.is_contiguous() and src.is_cuda

@@ -60,7 +60,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout_p = dropout            # dropout1 / dropout2 / dropout3 of the reference (msdeformattn.py:111-119), training mode only
-        self._masks = []                    # the keep-masks of the last training forward, in order (for tests)
+        self._masks = []                    # the keep-masks of the last UNFUSED training forward, in order (for tests)
+        self._seeds = None                  # the three dropout seeds of the last fused training forward (for tests)
 
     def _drop(self, t):
         """Inverted dropout with an explicit keep-mask (torch.nn.Dropout semantics: x * mask / keep_prob)."""
@@ -71,7 +72,14 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, level_embed=None):
         a = self.self_attn
-        if self.training and self.dropout_p > 0.0:
+        fusable = (level_embed is not None and pos is not None and padding_mask is None and reference_points.shape[-1] == 2
+                   and a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16)
+        drop = None
+        if self.training and self.dropout_p > 0.0 and fusable and not ops.is_exact():
+            # three seeds from torch's CPU generator (no device sync); the kernels derive the keep-masks from (seed, element index)
+            self._seeds = tuple(int(v) for v in torch.randint(0, 2 ** 31 - 1, (3,)).tolist())
+            drop = (float(self.dropout_p),) + self._seeds
+        elif self.training and self.dropout_p > 0.0:
             # training with dropout: the layer op by op (same kernels), masks applied between them as in the reference (:121-142)
             self._masks = []
             q = src if pos is None else src + pos
@@ -80,8 +88,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
             t = self._drop(F.relu(ops.linear(src, self.linear1.weight, self.linear1.bias)))
             t = ops.linear(t, self.linear2.weight, self.linear2.bias)
             return ops.layer_norm(src + self._drop(t.float()), self.norm2.weight, self.norm2.bias)
-        if (level_embed is not None and pos is not None and padding_mask is None and reference_points.shape[-1] == 2
-                and a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16):
+        if fusable:
             # the whole layer as one autograd node (ops.DeformEncoderLayerFn); `pos` is then a constant and the gradient of
             # the level embedding inside it is returned through `level_embed`
             return ops.deform_encoder_layer(
@@ -89,7 +96,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
                 [a.value_proj.weight, a.value_proj.bias, a.sampling_offsets.weight, a.sampling_offsets.bias,
                  a.attention_weights.weight, a.attention_weights.bias, a.output_proj.weight, a.output_proj.bias,
                  self.norm1.weight, self.norm1.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                 self.norm2.weight, self.norm2.bias])
+                 self.norm2.weight, self.norm2.bias], drop=drop)
         q = src if pos is None else src + pos
         h = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask, residual=src)
         src = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)

@@ -851,7 +851,7 @@ class DeformEncoderLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, src, pos, level_embed, ref, shapes, level_start, nH, nP,
+    def forward(ctx, src, pos, level_embed, ref, shapes, level_start, nH, nP, drop,
                 wv, bv, woff, boff, waw, baw, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2):
         B, S, C = src.shape
         M, L, D = B * S, shapes.shape[0], C // nH
@@ -867,18 +867,35 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         offaw = K.gemm_nt(q16, CACHE.cat(woff, waw), bias=CACHE.catvec(boff, baw), out_dtype=F32)   # (M, 3 nH L P) fp32
         loc, aw = K.msda_prep_fwd(offaw, ref, shapes, B, S, nH, L, nP)
         att = K.msdeform_attn_fwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, out_dtype=BF16).view(M, C)
-        h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
-        tw = []
-        s1, _, st1 = K.layernorm_fwd(h1, g1.detach(), b1.detach(), out_dtype=F32, twin=tw)
-        s1_16 = tw[0]
-        f = K.gemm_nt(s1_16, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_RELU)                # (M, ffn) bf16
-        h2 = K.gemm_nt(f, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=s1, out_dtype=F32)
-        tw = []
-        out, _, st2 = K.layernorm_fwd(h2, g2.detach(), b2.detach(), out_dtype=F32, twin=tw)
+        if drop is None or K.EXACT:
+            assert drop is None, "the fp32 verification mode has no dropout path"
+            h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
+            tw = []
+            s1, _, st1 = K.layernorm_fwd(h1, g1.detach(), b1.detach(), out_dtype=F32, twin=tw)
+            s1_16 = tw[0]
+            f = K.gemm_nt(s1_16, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_RELU)                # (M, ffn) bf16
+            h2 = K.gemm_nt(f, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=s1, out_dtype=F32)
+            tw = []
+            out, _, st2 = K.layernorm_fwd(h2, g2.detach(), b2.detach(), out_dtype=F32, twin=tw)
+        else:
+            # training: dropout1 / 2 / 3 of the reference layer (:111-142) between the same kernels.  The branch outputs leave their GEMMs
+            # as bf16, are masked in place (index-hash keep mask: nothing stored), and the residual sums move into the LayerNorm kernels.
+            pd, sd1, sd2, sd3 = drop
+            hb = K.dropout_bf16(K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach()), sd1, pd)
+            tw = []
+            s1, h1, st1 = K.layernorm_fwd(hb, g1.detach(), b1.detach(), res=x, out_dtype=F32, want_h=True, twin=tw)
+            s1_16 = tw[0]
+            f = K.gemm_nt(s1_16, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_RELU)
+            K.dropout_bf16(f, sd2, pd, out=f)
+            hb = K.dropout_bf16(K.gemm_nt(f, CACHE.mat(w2), bias=bb2.detach()), sd3, pd)
+            tw = []
+            out, h2, st2 = K.layernorm_fwd(hb, g2.detach(), b2.detach(), res=s1, out_dtype=F32, want_h=True, twin=tw)
+            del hb
         _register_twin(out, tw[0])                                                                 # the next layer's value / query operand source
         ctx.save_for_backward(x16, q16, value, loc, aw, att, h1, st1, s1_16, f, h2, st2, shapes, level_start,
                               wv, bv, woff, boff, waw, baw, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2)
         ctx.geom = (B, S, C, nH, nP)
+        ctx.drop = drop
         ctx.shapes_host = _host_shapes(shapes)
         return out.view(B, S, C)
 
@@ -896,7 +913,12 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         tw = []
         dh2 = K.layernorm_bwd(dy, h2, st2, g2.detach(), dgamma=gb(g2), dbeta=gb(b2), twin=tw)       # also the skip-path gradient of s1
         dh2_16 = tw[0]
-        df = K.gemm_nt(dh2_16, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DRELU, aux=f)                    # (M, ffn) bf16
+        drop = ctx.drop
+        inv_keep = 1.0
+        if drop is not None:            # the branch gradients are the masked, rescaled stream gradients; f > 0 <=> ReLU active AND kept
+            K.dropout_bf16(dh2_16, drop[3], drop[0], out=dh2_16)
+            inv_keep = 1.0 / (1.0 - drop[0])
+        df = K.gemm_nt(dh2_16, CACHE.mat_t(w2), epilogue=K.EPI_MUL_DRELU, aux=f, alpha=inv_keep)    # (M, ffn) bf16
         ds1 = K.gemm_nt(df, CACHE.mat_t(w1), epilogue=K.EPI_RESIDUAL, aux=dh2, out_dtype=F32)      # dh2 + dFFN-in
         if train:
             _tn(dh2_16, f, grad_buf(w2), grad_buf(bb2), (w2, bb2))
@@ -905,6 +927,8 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         tw = []
         dh1 = K.layernorm_bwd(ds1, h1, st1, g1.detach(), dgamma=gb(g1), dbeta=gb(b1), twin=tw)      # also the skip-path gradient of src
         dh1_16 = tw[0]
+        if drop is not None:
+            K.dropout_bf16(dh1_16, drop[1], drop[0], out=dh1_16)
         datt = K.gemm_nt(dh1_16, CACHE.mat_t(wo))                                                  # (M, C) bf16
         if train:
             _tn(dh1_16, att, grad_buf(wo), grad_buf(bo), (wo, bo))
@@ -926,11 +950,12 @@ class DeformEncoderLayerFn(torch.autograd.Function):
             sums = K.segment_colsum(doffaw, level_start, S, B)                                      # (L, ncol) fp32
             wcat = torch.cat([woff.detach().reshape(woff.shape[0], -1), waw.detach().reshape(waw.shape[0], -1)], 0)
             dlev = sums @ wcat
-        return (dsrc.view(B, S, C), None, dlev, None, None, None, None, None) + (None,) * 16
+        return (dsrc.view(B, S, C), None, dlev, None, None, None, None, None, None) + (None,) * 16
 
 
-def deform_encoder_layer(src, pos, level_embed, ref, shapes, level_start, nH, nP, params: Sequence[torch.Tensor]):
-    return DeformEncoderLayerFn.apply(src, pos, level_embed, ref, shapes, level_start, nH, nP, *params)
+def deform_encoder_layer(src, pos, level_embed, ref, shapes, level_start, nH, nP, params: Sequence[torch.Tensor], drop=None):
+    """drop: None, or (p, seed1, seed2, seed3) for the layer's three dropouts in training mode."""
+    return DeformEncoderLayerFn.apply(src, pos, level_embed, ref, shapes, level_start, nH, nP, drop, *params)
 
 
 # --------------------------------------------------------------------------------------------
