@@ -373,8 +373,9 @@ def main():
         tt = (time.perf_counter() - tt) / nt
         model.eval()
         extras["train_mode"] = {"ms_per_step": round(tt * 1e3, 3), "value": round(PER_GPU_BATCH / tt, 3), "unit": "img/s",
-                                "what": "model.train(): DropPath (dropped residual branches of a sample are skipped, kept ones scaled), "
-                                        "dropout 0.1 in the deformable encoder layers and the class transformer"}
+                                "what": "model.train(): DropPath 0..0.3 on both residual branches of every Swin block (per-image scale inside the GEMM "
+                                        "epilogues), dropout 0.1 in the deformable encoder layers (index-hash masks between the fused layer's kernels) "
+                                        "and in the class transformer (attention-probability dropout inside the attention kernels)"}
         try:
             loss = None
             buckets.zero_grad()

@@ -157,8 +157,8 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         src = torch.cat(srcs_tok, 1)
         a = self.encoder.layers[0].self_attn
         fused = a.d_model % 8 == 0 and a.d_model // a.n_heads in (16, 32, 64) and a.n_levels * a.n_points <= 16
-        if self.training and self.encoder.layers[0].dropout_p > 0.0:
-            fused = False                       # dropout masks sit between the layer's ops: composed path
+        if self.training and self.encoder.layers[0].dropout_p > 0.0 and ops.is_exact():
+            fused = False                       # fp32 verification mode: dropout through the composed path (explicit ATen masks)
         if fused:
             # pos = sine embedding + level embedding: a constant map for the fused layers (one period (S, C), shared by the
             # batch), which return the level embedding's gradient themselves

@@ -679,8 +679,18 @@ def _scale_vec(scales, device) -> torch.Tensor:
     if t is None:
         if len(_SCALE_VECS) > 4096:
             _SCALE_VECS.clear()
-        t = torch.tensor(list(scales), dtype=F32, device=device)
-        _SCALE_VECS[key] = t
+        B, c = len(scales), max(max(scales), 0.0)
+        if 0.0 < c and B <= 4:
+            # a block's branch only ever draws from {0, c}^B: upload all combinations in ONE copy the first time c is seen (an upload
+            # from pageable memory waits for the stream, so per-step misses would serialise host and GPU)
+            combos = [[c if (m >> b) & 1 else 0.0 for b in range(B)] for m in range(1 << B)]
+            allv = torch.tensor(combos, dtype=F32, device=device)
+            for m, row in enumerate(combos):
+                _SCALE_VECS[(tuple(row), str(device))] = allv[m]
+            t = _SCALE_VECS.get(key)
+        if t is None:
+            t = torch.tensor(list(scales), dtype=F32, device=device)
+            _SCALE_VECS[key] = t
     return t
 
 
