@@ -248,6 +248,66 @@ def test_full_model_forward_backward_golden(U):
     assert not bad, bad
 
 
+def test_full_model_training_mode(U):
+    """The whole model under model.train(): DropPath on every Swin block, dropout in the deformable encoder and the class transformer
+    (all inside the HIP path).  Random streams differ from the reference's by construction, so this checks what must hold for any draw:
+    finite loss and gradients, identical steps for identical seeds (forward bit for bit), different draws for different seeds, the same parameters
+    receiving gradients as in eval mode, and -- what the data-parallel bucket scheduler relies on -- exactly the calibrated number of
+    gradient-ready signals per parameter whatever was dropped."""
+    from oracle import torch_ref as T
+    from uenc.d2 import get_cfg, build_model
+    from uenc.config import add_common_config, add_swin_config, add_uni_encoder_config
+    from uenc.dp import GradBuckets
+    from uenc import ops
+    g = load_golden("model_fwd_bwd")
+    cfg = get_cfg()
+    add_common_config(cfg); add_swin_config(cfg); add_uni_encoder_config(cfg)
+    cfg.merge_from_list([
+        "MODEL.META_ARCHITECTURE", "OneFormer", "MODEL.BACKBONE.NAME", "D2SwinTransformer", "MODEL.SWIN.EMBED_DIM", 64,
+        "MODEL.SWIN.DEPTHS", [2, 2, 2, 2], "MODEL.SWIN.NUM_HEADS", [2, 4, 8, 16], "MODEL.SWIN.DROP_PATH_RATE", 0.5,
+        "MODEL.SEM_SEG_HEAD.NAME", "OneFormerHead",
+        "MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME", "MSDeformAttnPixelDecoder", "MODEL.SEM_SEG_HEAD.NUM_CLASSES", 19,
+        "MODEL.SEM_SEG_HEAD.CONVS_DIM", 256, "MODEL.SEM_SEG_HEAD.IN_FEATURES", ["res2", "res3", "res4", "res5"],
+        "MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS", 6, "MODEL.ONE_FORMER.TRANSFORMER_IN_FEATURE", "multi_scale_pixel_decoder",
+        "MODEL.ONE_FORMER.NUM_OBJECT_QUERIES", 150, "MODEL.ONE_FORMER.DEC_LAYERS", 10, "MODEL.IS_TRAIN", False,
+        "MODEL.PIXEL_MEAN", [123.675, 116.280, 103.530], "MODEL.PIXEL_STD", [58.395, 57.120, 57.375], "MODEL.DEVICE", "cuda"])
+    model = build_model(cfg)
+    _fill(model)
+    batch = [{"left_image": g["img0"].float(), "task": "The task is panoptic", "type": "segmentation"},
+             {"left_image": g["img1"].float(), "task": "The task is semantic", "type": "segmentation"}]
+    buckets = GradBuckets(model)
+
+    def step(seed, train=True):
+        model.train(train)
+        torch.manual_seed(seed)
+        buckets.zero_grad(); ops.begin_step(fresh_grads=True)
+        out, _ = model.forward_features(batch)
+        loss = T.synthetic_loss(out)
+        loss.backward()
+        buckets.finish()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return float(loss), grads
+
+    l_eval, g_eval = step(0, train=False)                   # calibration step of the buckets: eval mode
+    counted = list(buckets._expected)
+    losses = []
+    for seed in (1, 2, 3, 1):
+        loss, grads = step(seed)
+        assert buckets._count == counted, [i for i, (a, b) in enumerate(zip(buckets._count, counted)) if a != b][:8]
+        assert all(buckets._launched)
+        assert loss == loss and abs(loss) < 1e6 and all(bool(torch.isfinite(v).all()) for v in grads.values())
+        assert set(grads) == set(g_eval)
+        losses.append((loss, grads))
+    names = ("backbone.patch_embed.proj.weight", "sem_seg_head.pixel_decoder.transformer.encoder.layers.0.linear1.bias")
+    assert losses[0][0] == losses[3][0]                                                              # same seed: same draws, same forward
+    for n in names:          # ... and the same gradients up to float-atomics order; another seed's draws give other gradients
+        assert rel(losses[3][1][n], losses[0][1][n]) < 5e-2 and rel(losses[1][1][n], losses[0][1][n]) > 0.2, n      # (run-to-run: ~1e-2 on the deepest gradient)
+    assert len({round(l, 6) for l, _ in losses[:3]}) == 3 and all(abs(l - l_eval) > 1e-6 for l, _ in losses)   # other seeds: other draws
+    record_parity("train_mode/small_full_model", loss_eval=l_eval, loss_train_seeds_1_2_3=[l for l, _ in losses[:3]])
+    model.eval()
+    buckets.close()
+
+
 def test_full_size_swin_l_properties(U):
     """BASELINE configs[2] at its own size (Swin-L ws 12, 1024 x 2048): size-independent properties of the whole path, and the
     fp32 oracle's forward on one full-size image (about 15 s of CPU work) with the boolean attention masks pinned to it."""
