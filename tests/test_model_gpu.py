@@ -65,6 +65,37 @@ def test_swin_t_backbone_golden(U):
         assert rel(o[k], g[k]) < 1.5e-2, k
 
 
+def test_swin_t_backbone_full_size_config1(U):
+    """BASELINE configs[1] at its own size: the Swin-T backbone forward on 1024 x 2048 images (ws 7: 147 x 293 windows per image
+    at stage 1, no padding; bs 4 in the bench, `tools/config1_bench.py`).  One image against the fp32 oracle on the host (about 10 s of
+    CPU work) in both arithmetic modes, and batch independence over the four images of the configuration."""
+    import os
+    from oracle import fill, torch_ref as T
+    from uenc import ops
+    from uenc.modeling.backbone.swin import SwinTransformer
+    m = _fill(SwinTransformer(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7), "backbone.").cuda()
+    m.eval()
+    gen = torch.Generator().manual_seed(11)
+    imgs = (torch.randint(0, 256, (4, 3, 1024, 2048), generator=gen).float() - 120.0) / 58.0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = fill.state_dict_for(T.swin_param_shapes(T.SWIN_T))
+    with torch.no_grad():
+        want = T.swin_backbone(imgs[:1], sd, T.SWIN_T)
+        o4 = m(imgs.cuda())
+        o1 = m(imgs[:1].cuda())
+        ops.set_exact(True)
+        try:
+            oe = m(imgs[:1].cuda())
+        finally:
+            ops.set_exact(False)
+    figs = {}
+    for k in ("res2", "res3", "res4", "res5"):
+        assert tuple(o4[k].shape[1:]) == tuple(want[k].shape[1:]) and o4[k].shape[0] == 4
+        figs[k] = {"bf16": rel(o1[k], want[k]), "exact": rel(oe[k], want[k]), "batch_independence": rel(o4[k][:1], o1[k])}
+        assert figs[k]["bf16"] < 1.5e-2 and figs[k]["exact"] < 1e-4 and figs[k]["batch_independence"] < 1e-6, (k, figs[k])
+    record_parity("configs1/swin_t_backbone_1024x2048", **figs)
+
+
 def test_patch_merging_golden(U):
     from uenc.modeling.backbone.swin import PatchMerging
     g = load_golden("patch_merging")
