@@ -258,6 +258,7 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         # test hook: a list of (B, Q, S) bool masks replacing the thresholded predictions, so that parity tests can
         # pin the discrete attention-mask path to the reference's and measure the continuous arithmetic alone
+        self._mem_cache = {}                 # (B, H/4, W/4, device) -> sine-embedding tokens of the 1/4 map (see forward)
         self.forced_attn_masks = None
 
     @classmethod
@@ -305,7 +306,14 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         mf32 = self._tok(mask_features.float())
         if not mf32.is_contiguous():
             mf32 = mf32.contiguous()
-        mem = self.pe_layer.tokens(B, H4, W4, dev).contiguous()      # one materialised map: every layer's value projection reuses its bf16 copy
+        # one materialised map per geometry, kept across steps (it depends on the shape only): every layer's value projection reuses its
+        # bf16 copy (ops._twin), and neither the 268 MB expansion nor its cast is redone every step
+        mkey = (B, H4, W4, str(dev))
+        mem = self._mem_cache.get(mkey)
+        if mem is None:
+            self._mem_cache.clear()
+            mem = self.pe_layer.tokens(B, H4, W4, dev).contiguous()
+            self._mem_cache[mkey] = mem
         # (bf16 result: the sum only feeds the two key projections of the class transformer)
         key_in = ops.linear(mf32, self.class_input_proj.weight, self.class_input_proj.bias, residual=mem, out_dtype=K.adt())
         tgt = t_tok.expand(-1, Q - 1, -1) if self.use_task_norm else torch.zeros_like(qe[:, :-1])
