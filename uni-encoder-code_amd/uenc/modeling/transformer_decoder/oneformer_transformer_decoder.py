@@ -55,21 +55,16 @@ class MultiheadAttention(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim)
         nn.init.xavier_uniform_(self.in_proj_weight)
 
-    def forward(self, query, key, value, attn_mask=None, residual=None, kv=None):
-        """kv: (k, v) already projected with this module's in_proj rows (ops.multi_proj over the layers that share key / value)."""
+    def forward(self, query, key, value, attn_mask=None, residual=None):
         E = self.embed_dim
         W, b = self.in_proj_weight, self.in_proj_bias
-        if kv is not None:
-            q = ops.linear(query, W, b, rows=(0, E))
-            k, v = kv
-        elif query is key:
+        if query is key:
             qk = ops.linear(query, W, b, rows=(0, 2 * E))
             q, k = qk[..., :E], qk[..., E:]
         else:
             q = ops.linear(query, W, b, rows=(0, E))
             k = ops.linear(key, W, b, rows=(E, 2 * E))
-        if kv is None:
-            v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
+        v = ops.linear(value, W, b, rows=(2 * E, 3 * E))
         if self.training and self.dropout > 0.0:
             self.last_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)))      # torch's CPU generator: no device sync
             o = ops.attention(q, k, v, self.num_heads, attn_mask, self.dropout, self.last_seed)
@@ -103,10 +98,10 @@ class CrossAttentionLayer(nn.Module):
         self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.norm = nn.LayerNorm(d_model)
 
-    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None, key_in=None, kv=None):
+    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None, key_in=None):
         q = tgt if query_pos is None else tgt + query_pos
         k = key_in if key_in is not None else (memory if pos is None else memory + pos)
-        return _ln(self.norm, self.multihead_attn(q, k, memory, attn_mask=memory_mask, residual=tgt, kv=kv))
+        return _ln(self.norm, self.multihead_attn(q, k, memory, attn_mask=memory_mask, residual=tgt))
 
 
 class FFNLayer(nn.Module):
@@ -336,23 +331,13 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         predictions_class, predictions_mask = [], []         # (predictions_class collects the heads' normalised queries: see below)
         cls, msk, attn_mask = self.forward_prediction_heads(output, (mf16, H4, W4, mes), size_list[0])
         predictions_class.append(cls); predictions_mask.append(msk)
-        # key / value projections of all layers up front: the layers i, i + L, i + 2L, ... read the same level's memory, so their
-        # projections are one GEMM per level and kind over the stacked in_proj rows (ops.multi_proj), and each level's gradient
-        # arrives as one dgrad result instead of three tensors for the autograd engine to add
-        E, Lv = self.decoder_norm.normalized_shape[0], self.num_feature_levels
-        kproj, vproj = [], []
-        for lvl in range(Lv):
-            mods = [self.transformer_cross_attention_layers[i].multihead_attn for i in range(lvl, self.num_layers, Lv)]
-            lw = [(m.in_proj_weight, m.in_proj_bias) for m in mods]
-            kproj.append(ops.multi_proj(kin[lvl], lw, (E, 2 * E)))
-            vproj.append(ops.multi_proj(src[lvl], lw, (2 * E, 3 * E)))
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
             if self.forced_attn_masks is not None:
                 attn_mask = self.forced_attn_masks[i]
                 attn_mask = attn_mask & ~attn_mask.all(-1, keepdim=True)     # un-block fully blocked rows (:454)
             output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_mask=attn_mask, query_pos=qe,
-                                                                key_in=kin[lvl], kv=(kproj[lvl][i // Lv], vproj[lvl][i // Lv]))
+                                                                key_in=kin[lvl])
             output = self.transformer_self_attention_layers[i](output, query_pos=qe)
             output = self.transformer_ffn_layers[i](output)
             cls, msk, attn_mask = self.forward_prediction_heads(output, (mf16, H4, W4, mes),

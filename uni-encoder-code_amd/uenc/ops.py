@@ -556,62 +556,6 @@ def linear(x, weight, bias=None, *, residual=None, rows=None, out_dtype=None):
     return LinearFn.apply(x, weight, bias, residual, rows, out_dtype)
 
 
-class MultiProjFn(torch.autograd.Function):
-    """n Linear layers that read the SAME input (the key / value projections of the decoder layers that share a pyramid level: rows
-    [a, b) of each layer's packed in_proj weight) as ONE GEMM over the stacked weights: the input is read once, the outputs are
-    column slices of one (M, n * E) result, and the backward is one dgrad GEMM over all layers' gradients -- the input's gradient
-    arrives summed instead of as n tensors for the autograd engine to add."""
-
-    @staticmethod
-    def forward(ctx, x, rows, n, *wb):
-        Kd = x.shape[-1]
-        x2 = x.reshape(-1, Kd)
-        if x2.stride(1) != 1 or (x2.stride(0) % 8) != 0:
-            x2 = x2.contiguous()
-        ws, bs = wb[0::2], wb[1::2]
-        E = rows[1] - rows[0]
-        wc = torch.cat([CACHE.mat(w, rows) for w in ws], 0)                                   # (n E, K) bf16 / fp32
-        bc = torch.cat([b.detach()[rows[0]:rows[1]] for b in bs]).float() if bs[0] is not None else None
-        xp = _as_bf16_operand(x2)
-        out = K.gemm_nt(xp, wc, bias=bc, out_dtype=K.adt())
-        ctx.save_for_backward(xp, *wb)
-        ctx.cfg = (rows, n, E, x.shape, x.dtype)
-        o3 = out.view(*x.shape[:-1], n * E)
-        return tuple(o3[..., i * E:(i + 1) * E] for i in range(n))
-
-    @staticmethod
-    def backward(ctx, *dys):
-        xp, *wb = ctx.saved_tensors
-        rows, n, E, xshape, xdtype = ctx.cfg
-        ws, bs = wb[0::2], wb[1::2]
-        M = xp.shape[0]
-        dY = torch.empty((M, n * E), dtype=K.adt(), device=xp.device)
-        for i, d in enumerate(dys):
-            if d is None:
-                dY[:, i * E:(i + 1) * E].zero_()
-            else:
-                dY[:, i * E:(i + 1) * E].copy_(d.reshape(M, E))
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wt = torch.cat([CACHE.mat_t(w, rows) for w in ws], 1).contiguous()                # (K, n E)
-            dx = K.gemm_nt(dY, wt, out_dtype=_odt_like(xdtype)).reshape(xshape)
-        for i, (w, b) in enumerate(zip(ws, bs)):
-            _wgrad(dY[:, i * E:(i + 1) * E], xp, w, b, rows)
-        return (dx, None, None) + (None,) * len(wb)
-
-
-def _odt_like(dtype):
-    return F32 if (dtype == F32 or K.EXACT) else BF16
-
-
-def multi_proj(x, layers, rows):
-    """[x W_i[rows]^T + b_i[rows] for (W_i, b_i) in layers] from one GEMM; each result is a (.., E) column slice of one buffer."""
-    flat = []
-    for w, b in layers:
-        flat += [w, b]
-    return MultiProjFn.apply(x, rows, len(layers), *flat)
-
-
 class MLPFn(torch.autograd.Function):
     """x -> [Linear -> act] x (n-1) -> Linear (+ residual).  act in {"relu", "gelu"}.
 
