@@ -13,7 +13,7 @@
  *   - return 0 = launched, < 0 = invalid argument (shape / alignment / dtype; nothing was launched),
  *     > 0 = hipError_t from the launch;
  *   - the caller owns every buffer (inputs, outputs, scratch); the library allocates nothing, never
- *     synchronises, and launches on the given stream (`hipStream_t`, passed as void*);
+ *     synchronises, and launches on the given stream (`uenc_stream_t` = `hipStream_t`, passed as void*);
  *   - stateless and re-entrant, with one opt-in exception: the `uenc_prof_*` launch timers;
  *   - dtype tags: UENC_F32 = 0, UENC_BF16 = 1.  bf16 operands, fp32 accumulation everywhere.
  *   - gfx950 only.
@@ -29,6 +29,14 @@ extern "C" {
 #define UENC_F32 0
 #define UENC_BF16 1
 
+/* The launch stream.  A HIP stream handle is a pointer; C callers (ctypes, cgo, JNI) pass it as void*.  The library's own
+ * sources define UENC_STREAM_T as hipStream_t before including this header, so that hipcc checks every definition in
+ * the csrc .hip files against the declaration here (same ABI: one pointer). */
+#ifndef UENC_STREAM_T
+#define UENC_STREAM_T void*
+#endif
+typedef UENC_STREAM_T uenc_stream_t;
+
 /* GEMM epilogues */
 #define UENC_EPI_NONE 0       /* C = alpha * (A W^T + bias)                                   */
 #define UENC_EPI_GELU 1       /* C = gelu(.) (erf form); optional aux_out <- pre-activation    */
@@ -41,45 +49,44 @@ int uenc_version(void);
 const char* uenc_arch(void); /* "gfx950" */
 
 /* ---- casts: fp32 master weights -> bf16 MFMA operands (replaces autocast-style .to(bf16)) ---------- */
-int uenc_cast_f32_bf16(const float* src, void* dst, long n /* Inverted dropout on a bf16 tensor of n elements (n % 8 == 0; in place allowed): out[i] = keep(i) ? in[i] / (1 - p) : 0 with
+int uenc_cast_f32_bf16(const float* src, void* dst, long n /* multiple of 8 */, uenc_stream_t stream);
+/* Inverted dropout on a bf16 tensor of n elements (n % 8 == 0; in place allowed): out[i] = keep(i) ? in[i] / (1 - p) : 0 with
  * keep(i) = hash(seed, i) >= p * 2^32 (the index hash the attention kernels use for attention-probability dropout).  The mask is a
  * function of (seed, i): the backward calls the same entry on the gradient.  Replaces nn.Dropout between the deformable encoder
  * layer's kernels in training mode (reference pixel_decoder/msdeformattn.py:111-119, 121-142). */
-int uenc_dropout_bf16(const void* in, void* out, long n, unsigned seed, float p, void* stream);
-
-/* multiple of 8 */, void* stream);
-int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C][R] bf16 */, int R, int C, void* stream);
+int uenc_dropout_bf16(const void* in, void* out, long n, unsigned seed, float p, uenc_stream_t stream);
+int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C][R] bf16 */, int R, int C, uenc_stream_t stream);
 
 /* batched cast: `table` = n device-resident descriptors {const float* src; bf16* dst; int rows, cols, transpose, tiles_c;
  * long tile_begin;} (40 bytes each; tiles_c = ceil(cols / 64), tile_begin = exclusive prefix sum of 64x64 tile counts);
  * dst is [rows][cols] or, if transpose, [cols][rows].  One launch refreshes every bf16 weight operand of a model. */
-int uenc_cast_multi(const void* table, int n, long total_tiles, void* stream);
+int uenc_cast_multi(const void* table, int n, long total_tiles, uenc_stream_t stream);
 
 /* bilinear resize, align_corners = False, of NC fp32 planes (Hi, Wi) -> (Ho, Wo), Wo % 4 == 0: the final mask upsample
  * F.interpolate(mask_pred_results, size=..., mode="bilinear") of model/oneformer_model.py:255-263 (forward only). */
-int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, void* stream);
+int uenc_upsample_bilinear(const float* in, float* out, long NC, int Hi, int Wi, int Ho, int Wo, uenc_stream_t stream);
 
 /* attention mask of the masked-attention decoder: mask[r][oy][ox] = bilinear(logits[r], (Ho, Wo))[oy][ox] < 0 (1 = blocked),
  * rows that would be fully blocked are cleared (reference oneformer_transformer_decoder.py:497-505 and :454).
  * logits fp32 [rows][Hi][Wi]; mask u8 [rows][Ho][Wo]. */
-int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, void* stream);
+int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int Hi, int Wi, int Ho, int Wo, uenc_stream_t stream);
 
 /* ---- glue of the deformable encoder layer (pixel_decoder/ops/modules/ms_deform_attn.py:91-113) ---------------------
  * out = bf16(a + b), b repeating every `period` elements (n % period == 0, both % 4 == 0): query = src + pos. */
-int uenc_add_cast_bf16(const float* a, const float* b, void* out, long n, long period, void* stream);
+int uenc_add_cast_bf16(const float* a, const float* b, void* out, long n, long period, uenc_stream_t stream);
 /* offaw (rows, ld) fp32 = [M][L][P][2] sampling offsets | [M][L*P] attention logits per row (row = image * Lq + query):
  * loc (rows, M, L, P, 2) = ref + off / (W_l, H_l), aw (rows, M, L*P) = softmax(logits).  ref (N|1, Lq, L, 2) fp32
  * (ref_per_image: 1 if it has a batch dimension), shapes (L, 2) int64 device.  L * P <= 16. */
 int uenc_msda_prep_fwd(const float* offaw, long ld, const float* ref, int ref_per_image, const int64_t* shapes, float* loc,
-                       float* aw, long rows, int Lq, int M, int L, int P, void* stream);
+                       float* aw, long rows, int Lq, int M, int L, int P, uenc_stream_t stream);
 /* doffaw (rows, ld) bf16 <- d(loc), d(aw) and the saved softmax aw. */
 int uenc_msda_prep_bwd(const float* dloc, const float* daw, const float* aw, const int64_t* shapes, void* doffaw, long ld,
-                       long rows, int Lq, int M, int L, int P, void* stream);
+                       long rows, int Lq, int M, int L, int P, uenc_stream_t stream);
 /* out (nseg, 128, cols) fp32 = 128 partial column sums per segment (the caller adds them) of the bf16 matrix x16 over row
  * segments [seg_start[s], seg_start[s+1]) of every image (rows_per_image rows each): per-level sums for the level-embedding
  * gradient.  cols % 8 == 0. */
 int uenc_segment_colsum(const void* x16, long ld, int cols, const int64_t* seg_start, int nseg, long rows_per_image, int images,
-                        float* out, void* stream);
+                        float* out, uenc_stream_t stream);
 
 /* ---- FPN branch of the pixel decoder on token matrices (pixel_decoder/msdeformattn.py:283-304, :343-352) -----------
  * y = GroupNorm(x) [+ bilinear_resize(add_src, align_corners=False)] [ReLU] for x, y (B, HW, C) fp32|bf16 (torch.nn.GroupNorm
@@ -89,23 +96,23 @@ int uenc_segment_colsum(const void* x16, long ld, int cols, const int64_t* seg_s
 long uenc_groupnorm_tokens_scratch_bytes(int B, int HW, int C, int G);
 int uenc_groupnorm_tokens_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                               float* stats, void* scratch, const float* add_src, int Hs, int Ws, int H, int W, int B, int HW,
-                              int C, int G, float eps, int relu, void* stream);
+                              int C, int G, float eps, int relu, uenc_stream_t stream);
 /* dx (B, HW, C) fp32|bf16; dgamma / dbeta (C) accumulated (may be NULL); relu != 0: the mask is recomputed from x. */
 int uenc_groupnorm_tokens_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
                               const float* stats, void* dx, int dx_dtype, float* dgamma, float* dbeta, void* scratch, int B,
-                              int HW, int C, int G, int relu, void* stream);
+                              int HW, int C, int G, int relu, uenc_stream_t stream);
 /* adjoint of the bilinear merge: dsrc (B, Hs, Ws, C) fp32 overwritten from dy (B, H, W, C) fp32|bf16, H >= Hs, W >= Ws. */
 int uenc_upsample_bilinear_tokens_bwd(const void* dy, int dy_dtype, float* dsrc, int B, int H, int W, int Hs, int Ws, int C,
-                                      void* stream);
+                                      uenc_stream_t stream);
 /* 3x3 / stride 1 / pad 1 convolution as a GEMM (bf16, C % 8 == 0): col (B*H*W, 9*C) with column (ky, kx, c) from
  * in (B, H, W, C), and the adjoint dx (B, H, W, C) from dcol (B*H*W, 9*C). */
-int uenc_im2col3x3(const void* in, void* col, int B, int H, int W, int C, void* stream);
-int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, void* stream);
+int uenc_im2col3x3(const void* in, void* col, int B, int H, int W, int C, uenc_stream_t stream);
+int uenc_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, uenc_stream_t stream);
 /* The same for the 3x3 stride-2 pad-1 convolutions of DiNAT's ConvTokenizer / ConvDownsampler (reference
  * model/modeling/backbone/dinat.py:17-45): col (B * ceil(H/2) * ceil(W/2), 9C) bf16 in (ky, kx, c) order; the adjoint gathers
  * dcol back to dx (B, H, W, C) fp32, every element written once.  C % 8 == 0. */
-int uenc_im2col3x3_s2(const void* in, void* col, int B, int H, int W, int C, void* stream);
-int uenc_col2im3x3_s2(const void* dcol, float* dx, int B, int H, int W, int C, void* stream);
+int uenc_im2col3x3_s2(const void* in, void* col, int B, int H, int W, int C, uenc_stream_t stream);
+int uenc_col2im3x3_s2(const void* dcol, float* dx, int B, int H, int W, int C, uenc_stream_t stream);
 
 /* ---- Linear layers ---------------------------------------------------------------------------------
  * C[m][n] = epi(alpha * (sum_k A[m][k] W[n][k] + bias[n])).  A fp32|bf16 [M][K] (lda), W bf16 [N][K] (ldw),
@@ -117,36 +124,36 @@ int uenc_col2im3x3_s2(const void* dcol, float* dx, int B, int H, int W, int C, v
  *   and nn.MultiheadAttention's in/out projections (transformer.py:252-253). */
 int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                  int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
-                 void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, void* stream);
+                 void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, uenc_stream_t stream);
 /* The same with alpha multiplied per SAMPLE: row m uses alpha * sample_scale[m / rows_per_sample] (sample_scale: device fp32).
  * Stochastic depth as an epilogue -- timm DropPath(x) = x * floor(keep + U) / keep per image (reference backbone/swin.py:8, 279, 289):
  * the residual-branch GEMM runs over all images at once, a dropped image's rows come out as the residual alone.  Stored results only. */
 int uenc_gemm_nt_scaled(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                         int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
-                        void* aux_out, long ldaux_out, float alpha, const float* sample_scale, int rows_per_sample, void* stream);
+                        void* aux_out, long ldaux_out, float alpha, const float* sample_scale, int rows_per_sample, uenc_stream_t stream);
 /* Split-K with STORED partial sums (no atomics): split s of `splitk` writes its fp32 partial product to P + s * part_stride
  * (row stride ldp); the caller sums the slices.  splitk must equal uenc_gemm_nt_splits(K, requested) (the number of non-empty
  * k-ranges after rounding to 64).  Replaces the reference's torch.einsum("bqc,bchw->bqhw") backward w.r.t. the mask embedding
  * (model/modeling/transformer_decoder/oneformer_transformer_decoder.py:500) for all prediction heads at once. */
 int uenc_gemm_nt_splits(int K, int splitk);
 int uenc_gemm_nt_partials(const void* A, int a_dtype, long lda, const void* W, long ldw, float* P, long ldp, long part_stride,
-                          int M, int N, int K, float alpha, int splitk, void* stream);
+                          int M, int N, int K, float alpha, int splitk, uenc_stream_t stream);
 
 /* `batch` problems of one shape in one launch (problem b: A + b*bsA, W + b*bsW -> C + b*bsC, element strides, byte
  * offsets multiples of 16); no bias / epilogue; split-K and accumulate as above. */
 int uenc_gemm_nt_batched(const void* A, int a_dtype, long lda, long bsA, const void* W, long ldw, long bsW, void* C, int c_dtype,
-                         long ldc, long bsC, int batch, int M, int N, int K, float alpha, int splitk, int accumulate, void* stream);
+                         long ldc, long bsC, int batch, int M, int N, int K, float alpha, int splitk, int accumulate, uenc_stream_t stream);
 
 /* weight / bias gradient of the same Linear:  dW[n][k] += sum_m dY[m][n] X[m][k];  db[n] += sum_m dY[m][n]
  * (db may be NULL).  dY, X fp32|bf16 row-major; dW, db fp32, accumulated (atomics).  N % 8 == K % 8 == 0.
  * splitm <= 0 lets the library choose the split of the token dimension.  Replaces autograd's
  * mm / sum backward of every Linear above. */
 int uenc_gemm_tn(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
-                 float* db, int M, int N, int K, int splitm, void* stream);
+                 float* db, int M, int N, int K, int splitm, uenc_stream_t stream);
 /* dW += alpha * dY^T X, db += alpha * column sums: the weight gradient of a residual branch whose output was scaled by alpha
  * (stochastic depth, timm DropPath at reference backbone/swin.py:279, 289; the branch's dropped images are left out of M). */
 int uenc_gemm_tn_scaled(const void* dY, int dy_dtype, long ldy, const void* X, int x_dtype, long ldx, float* dW, long ldw,
-                        float* db, int M, int N, int K, int splitm, float alpha, void* stream);
+                        float* db, int M, int N, int K, int splitm, float alpha, uenc_stream_t stream);
 
 /* Grouped weight gradients: one launch for many (dY, X, dW, db) problems of the form above (bf16 operands only).
  * table: n descriptors in DEVICE memory, 96 bytes each:
@@ -156,11 +163,11 @@ int uenc_gemm_tn_scaled(const void* dY, int dy_dtype, long ldy, const void* X, i
  * sum of ceil(N / tile) * tiles_k * nsplit; total_items = the full sum.  tile = 256 or 128.  Accumulates into dW / db
  * (atomic adds), or, for a descriptor with store != 0 and nsplit == 1, overwrites them with plain stores.
  * flops = 2 * sum(M N K), used by uenc_prof_* only. */
-int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, void* stream);
+int uenc_gemm_tn_grouped(const void* table, int n, int total_items, int tile, double flops, uenc_stream_t stream);
 /* The same for the register-staged kernel (any M, fp32|bf16 operands, 128 x 128 tiles): descriptors of 96 bytes
  *   { const void* dY, *X; float* dW, *db; long ldy, ldx, ldw; int M, N, K, dy_f32, x_f32, tiles_k, mlen, nsplit, item_begin; float alpha; }   (alpha: as above)
  * tiles_k = ceil(K / 128), mlen % 64 == 0, item_begin = exclusive prefix sum of ceil(N / 128) * tiles_k * nsplit. */
-int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double flops, void* stream);
+int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double flops, uenc_stream_t stream);
 
 /* ---- LayerNorm over the last dimension (C % 4 == 0, C <= 6144) --------------------------------------
  * y = LN(x + res) * gamma + beta; optional h_out <- x + res (fp32); optional stats <- (mean, rstd) per row.
@@ -168,22 +175,22 @@ int uenc_gemm_tn_grouped_small(const void* table, int n, int total_items, double
  * msdeformattn.py:128-129,136-137, transformer.py:268-297, oneformer_transformer_decoder.py:66-67,126-127,184-185,496. */
 int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtype, float* h_out, const float* gamma,
                        const float* beta, void* y, int y_dtype, float* stats, long M, int C, float eps, void* y16,
-                       void* stream);
+                       uenc_stream_t stream);
 /* dx = LN'(dy) [+ dres];  dgamma / dbeta accumulated (both NULL to skip).
  * y16 / dx16 (may be NULL): a bf16 copy of y / dx written in the same pass -- the operand the next GEMM reads, so that an
  * fp32 stream needs no separate cast kernel.  part_ws (may be NULL): scratch of 2048 * 2 * C floats; with it the
  * workgroups' dgamma / dbeta partials are stored and summed by a second small kernel instead of added atomically. */
 int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats, const float* gamma,
                        const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* dx16,
-                       float* part_ws, void* stream);
+                       float* part_ws, uenc_stream_t stream);
 /* PatchMerging's pad-to-even + 2x2 strided gather + concat (order (0,0), (1,0), (0,1), (1,1)) + LayerNorm(4C) as one pass
  * (reference model/modeling/backbone/swin.py:311-334; the 4C -> 2C reduction GEMM follows): x (B, H, W, C) fp32 ->
  * y (B * ceil(H/2) * ceil(W/2), 4C) bf16, stats (rows, 2).  Backward: dy (rows, 4C) bf16 | fp32 -> dx (B, H, W, C) fp32 written
  * completely; dgamma / dbeta (4C) accumulated; part_ws as for uenc_layernorm_bwd. */
 int uenc_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, void* y, float* stats, int B, int H, int W,
-                            int C, float eps, void* stream);
+                            int C, float eps, uenc_stream_t stream);
 int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* stats, const float* gamma, float* dx,
-                            float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, void* stream);
+                            float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, uenc_stream_t stream);
 
 /* ---- shifted-window attention (head_dim 32, window <= 12) ---------------------------------------------
  * Replaces F.pad -> torch.roll -> window_partition -> WindowAttention core -> window_reverse -> roll -> crop,
@@ -192,9 +199,9 @@ int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const 
  * bias_q / bias_k: expanded relative-position bias from uenc_relpos_expand; out (B,H,W,C) bf16. */
 int uenc_window_attn_np(int ws); /* padded tokens per window = 16 * ceil(ws*ws / 16) */
 int uenc_relpos_expand(const float* table /* ((2ws-1)^2, nH) */, float* bias_q /* (nH,NP,NP) [h][q][key] */,
-                       float* bias_k /* (nH,NP,NP) [h][key][q] */, int nH, int ws, void* stream);
+                       float* bias_k /* (nH,NP,NP) [h][key][q] */, int nH, int ws, uenc_stream_t stream);
 int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
-                         int C, int nH, int ws, int shift, float scale, void* stream);
+                         int C, int nH, int ws, int shift, float scale, uenc_stream_t stream);
 /* dqkv (B,H,W,3C) bf16 written.  dS_ws: scratch of uenc_window_attn_bwd_ws_floats() floats (dense per-workgroup sums of
  * dS, overwritten).  The two parameter gradients are ACCUMULATED (+=, float atomics) straight into the caller's buffers, i.e.
  * into attn.relative_position_bias_table.grad and attn.qkv.bias.grad: dtable ((2ws-1)^2, nH) fp32 in the parameter's own
@@ -203,7 +210,7 @@ int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bia
 long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws);
 int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
                          const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
-                         int B, int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
+                         int B, int H, int W, int C, int nH, int ws, int shift, float scale, uenc_stream_t stream);
 
 /* ---- multi-scale deformable attention: the reference's native op ---------------------------------------
  * ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
@@ -213,7 +220,7 @@ int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bia
  * one launch covers the batch. */
 int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
                            const float* loc, const float* attn, void* out, int out_dtype, int B, int S, int M, int D,
-                           int L, int Lq, int P, void* stream);
+                           int L, int Lq, int P, uenc_stream_t stream);
 /* ms_deform_attn_backward (ms_deform_attn.h:47-66, cuh:306-408): grad_value fp32 accumulated (caller zeroes,
  * as the reference's at::zeros_like), grad_loc / grad_attn overwritten.  shapes_host: optional HOST copy of `shapes`,
  * workspace: optional device scratch of uenc_msdeform_attn_bwd_workspace_bytes() bytes (both may be NULL).  With them
@@ -222,7 +229,7 @@ int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int64_t* shapes
 int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
                            const float* loc, const float* attn, const void* grad_out, int go_dtype, float* grad_value,
                            float* grad_loc, float* grad_attn, int B, int S, int M, int D, int L, int Lq, int P,
-                           const int64_t* shapes_host, void* workspace, long workspace_bytes, void* stream);
+                           const int64_t* shapes_host, void* workspace, long workspace_bytes, uenc_stream_t stream);
 long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, int M, int D, int L, int Lq, int P);
 
 /* ---- decoder multi-head attention core (head_dim 32) --------------------------------------------------------
@@ -239,13 +246,13 @@ long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, i
 long uenc_mha_fwd_workspace_floats(int B, int H, int Lq, int S);
 int uenc_mha_fwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
                  long v_rs, const unsigned char* mask, long mask_rs, void* out, long o_bs, long o_rs, float* lse,
-                 float* workspace, int B, int H, int Lq, int S, float scale, float dropout_p, unsigned seed, void* stream);
+                 float* workspace, int B, int H, int Lq, int S, float scale, float dropout_p, unsigned seed, uenc_stream_t stream);
 /* dq (B,Lq,*) fp32 ACCUMULATED (caller zeroes); dk, dv (B,S,*) bf16 overwritten for every key and head. */
 int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v, long v_bs,
                  long v_rs, const unsigned char* mask, long mask_rs, const void* out, long o_bs, long o_rs,
                  const float* lse, const void* dout, long do_bs, long do_rs, float* dq, long dq_bs, long dq_rs, void* dk,
                  long dk_bs, long dk_rs, void* dv, long dv_bs, long dv_rs, int B, int H, int Lq, int S, float scale,
-                 float dropout_p, unsigned seed, void* stream);
+                 float dropout_p, unsigned seed, uenc_stream_t stream);
 
 /* ---- neighbourhood attention 2-D (DiNAT backbone) -------------------------------------------------------------
  * What natten.NeighborhoodAttention2D computes between its qkv and proj Linear layers (reference call site
@@ -255,11 +262,11 @@ int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, long k_bs, 
  * bf16; lse (B, nH, H, W) fp32 natural-log log-sum-exp (NULL for inference).  K odd in 3..13; H, W >= K * dilation (the
  * caller zero-pads smaller inputs first, as NATTEN does); scale = head_dim^-0.5 applied to q.k. */
 int uenc_na2d_fwd(const void* qkv, const float* rpb, void* out, float* lse, int B, int H, int W, int nH, int K, int dilation,
-                  float scale, void* stream);
+                  float scale, uenc_stream_t stream);
 /* dqkv (B, H, W, 3, nH, 32) bf16 overwritten completely; drpb (nH, 2K-1, 2K-1) fp32 ACCUMULATED (may be NULL);
  * delta_ws: B * nH * H * W floats of scratch. */
 int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out, const void* dout, const float* lse, void* dqkv, float* drpb,
-                  float* delta_ws, int B, int H, int W, int nH, int K, int dilation, float scale, void* stream);
+                  float* delta_ws, int B, int H, int W, int nH, int K, int dilation, float scale, uenc_stream_t stream);
 
 /* ---- segmentation post-processing fused with the mask upsample (inference) ---------------------------------------
  * The reference upsamples the (Q, h, w) mask logits to the padded input size (model/oneformer_model.py:255-263), crops the
@@ -273,11 +280,11 @@ int uenc_na2d_bwd(const void* qkv, const float* rpb, const void* out, const void
  *                    reads back with three .item() syncs per query (:399-408)
  *   panoptic_label:  seg (Ho, Wo) = segid[ids] where that query's sigmoid >= 0.5, else 0 (:420-425); segid (Q), 0 = dropped */
 int uenc_postproc_semantic(const float* mask_logits, const float* class_prob, float* sem, int Q, int C, int Cp, int hl, int wl,
-                           int Hp, int Wp, int Ho, int Wo, void* stream);
+                           int Hp, int Wp, int Ho, int Wo, uenc_stream_t stream);
 int uenc_postproc_panoptic_stats(const float* mask_logits, const float* score, int* ids, int* counts, int Q, int hl, int wl, int Hp,
-                                 int Wp, int Ho, int Wo, void* stream);
+                                 int Wp, int Ho, int Wo, uenc_stream_t stream);
 int uenc_postproc_panoptic_label(const float* mask_logits, const int* ids, const int* segid, int* seg, int Q, int hl, int wl, int Hp,
-                                 int Wp, int Ho, int Wo, void* stream);
+                                 int Wp, int Ho, int Wo, uenc_stream_t stream);
 
 /* ---- fp32 "exact" arithmetic mode (csrc/exact.hip; UENC_EXACT=1 / uenc.ops.set_exact) -----------------------------------
  * The reference computes in fp32 end to end (AMP off, configs/cityscapes/swin/unified_encoder_cityscapes.yaml:27-28; the pixel
@@ -294,19 +301,19 @@ int uenc_postproc_panoptic_label(const float* mask_logits, const int* ids, const
  *   mha_f32_{fwd,bwd}: the decoder's nn.MultiheadAttention cores, tensor contract of uenc_mha_* with fp32 tensors; lse (B, nH, Lq);
  *                 bwd: dq written, dk / dv (zeroed by the caller) accumulated, delta (B, nH, Lq) scratch */
 int uenc_gemm_nt_f32(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias,
-                     int epilogue, const float* aux, long ldaux, float* aux_out, long ldaux_out, float alpha, int accumulate, void* stream);
-int uenc_gemm_tn_f32(const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db, int M, int N, int K, void* stream);
+                     int epilogue, const float* aux, long ldaux, float* aux_out, long ldaux_out, float alpha, int accumulate, uenc_stream_t stream);
+int uenc_gemm_tn_f32(const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db, int M, int N, int K, uenc_stream_t stream);
 int uenc_window_attn_f32_fwd(const float* qkv, const float* qkv_bias, const float* table, float* out, int B, int H, int W, int C, int nH,
-                             int ws, int shift, float scale, void* stream);
+                             int ws, int shift, float scale, uenc_stream_t stream);
 int uenc_window_attn_f32_bwd(const float* qkv, const float* qkv_bias, const float* table, const float* dout, float* dqkv, float* dtable,
-                             float* dbias_pad, int B, int H, int W, int C, int nH, int ws, int shift, float scale, void* stream);
+                             float* dbias_pad, int B, int H, int W, int C, int nH, int ws, int shift, float scale, uenc_stream_t stream);
 int uenc_mha_f32_fwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
                      const uint8_t* mask, long mask_row_stride, float* out, long os0, long os1, float* lse, int B, int nH, int Lq, int S,
-                     float scale, float dropout_p, unsigned seed, void* stream);
+                     float scale, float dropout_p, unsigned seed, uenc_stream_t stream);
 int uenc_mha_f32_bwd(const float* q, long qs0, long qs1, const float* k, long ks0, long ks1, const float* v, long vs0, long vs1,
                      const uint8_t* mask, long mask_row_stride, const float* out, long os0, long os1, const float* lse, const float* dout,
                      long gos0, long gos1, float* dq, long dqs0, long dqs1, float* dk, long dks0, long dks1, float* dv, long dvs0, long dvs1,
-                     float* delta, int B, int nH, int Lq, int S, float scale, float dropout_p, unsigned seed, void* stream);
+                     float* delta, int B, int nH, int Lq, int S, float scale, float dropout_p, unsigned seed, uenc_stream_t stream);
 
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */

@@ -30,6 +30,33 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/uenc.h but not exported"
 
 
+@pytest.mark.parametrize("cc,lang,std", [("gcc", "c", "-std=c99"), ("gcc", "c", "-std=c11"), ("g++", "c++", "-std=c++11")])
+def test_header_is_valid_c_and_cxx(cc, lang, std):
+    """include/uenc.h compiles on its own as C and as C++ (round 2 shipped a header with a declaration pasted into another one's
+    parameter list: nothing compiled it)."""
+    import subprocess
+    r = subprocess.run([cc, "-fsyntax-only", "-x", lang, std, "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "include", "uenc.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_every_kernel_source_is_compiled_against_the_header():
+    """Each csrc/*.hip includes common.h, which includes include/uenc.h with UENC_STREAM_T = hipStream_t: a definition whose
+    signature drifts from its declaration is a hipcc error ("conflicting types"), so the build is the type check."""
+    csrc = os.path.join(ROOT, "uni-encoder-code_amd", "csrc")
+    common = open(os.path.join(csrc, "common.h")).read()
+    assert '#include "../../include/uenc.h"' in common and "#define UENC_STREAM_T hipStream_t" in common
+    hips = [f for f in os.listdir(csrc) if f.endswith(".hip")]
+    assert len(hips) >= 12
+    defined = set()
+    for f in hips:
+        src = open(os.path.join(csrc, f)).read()
+        assert '#include "common.h"' in src, f
+        defined |= set(re.findall(r'extern "C"\s+(?:const\s+)?\w+\*?\s+(uenc_[a-z0-9_]+)\s*\(', src))
+    # nothing is exported that the header does not declare, and nothing declared lacks a definition
+    assert defined == set(_declared()), (defined ^ set(_declared()))
+
+
 def test_python_binding_matches_header():
     from uenc import capi
     assert set(capi.exported_symbols()) == set(_declared())

@@ -25,8 +25,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         return e__ == hipSuccess ? UENC_OK : (int)e__; \
     } while (0)
 
-// dtype tags used across the C ABI
-enum { UENC_F32 = 0, UENC_BF16 = 1 };
+// The C ABI itself (dtype tags, epilogue codes, every entry point): each definition in csrc/*.hip is compiled against its
+// declaration, so hipcc rejects any drift between include/uenc.h and the library.
+#define UENC_STREAM_T hipStream_t
+#include "../../include/uenc.h"
 
 // D = A(16x32) * B(32x16) + C, bf16 in / fp32 acc.
 //  A fragment: lane l holds A[row l&15][k = 8*(l>>4) .. +7]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 
+#include "common.h"
 #include "prof.h"
 
 namespace {
