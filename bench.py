@@ -239,6 +239,38 @@ def dp_check(model, buckets, batches, step_fn, rank, world, device):
     return rec
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without torchrun: start the N ranks here, one process per GPU, the way the reference's
+    detectron2.engine.launch does (train_net.py:302-309) -- as a child `torch.distributed.run` started BEFORE this process makes
+    any GPU call (never an exec from a process that has initialised the GPU), and exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks through torch.distributed.run on 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def _rendezvous_only(args, world, rank):
+    """Plumbing check of the N > 1 entry (CPU test, gloo): rendezvous, barrier, the MAX-over-ranks reduction of the timed region,
+    rank 0's JSON line -- no model, no GPU, `value` null."""
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "img/s fwd+bwd Swin-L 1024x2048 bs=2 per GPU", "value": None, "unit": "img/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "rendezvous_only": True, "config": {"parallelism": f"dp{world}"}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,13 +280,24 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip forward-only / train-mode / eager-baseline legs (profiling runs)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--check-dp", default="", help="N > 1: verify the reduced gradients against single-rank passes, write this JSON")
+    ap.add_argument("--rendezvous-only", action="store_true", help="N ranks rendezvous over gloo and print the line's skeleton (CPU plumbing test)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))          # never report dp1 for --gpus N: start the ranks, or fail with the child's code
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}, "
+                         "or plain `python bench.py --gpus N`, which launches them itself)")
+    if args.rendezvous_only:
+        return _rendezvous_only(args, world, rank)
+    if world > max(torch.cuda.device_count(), 1) and os.environ.get("UENC_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible (RCCL needs one device per rank; "
+                         "UENC_DIST_BACKEND=gloo runs a functional rehearsal of more ranks than GPUs)")
     local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"

@@ -153,7 +153,7 @@ def _diverging_worker(rank, world, port, q):
         gb.finish()
         q.put((rank, "no error", w0))
     except RuntimeError as e:
-        q.put((rank, "raised" if "differ from rank 0" in str(e) else repr(e), w0))
+        q.put((rank, "raised" if "differ from rank 0 on rank(s) 1 " in str(e) else repr(e), w0))
     dist.destroy_process_group()
 
 
@@ -175,4 +175,30 @@ def test_replicas_are_broadcast_and_a_diverging_rank_is_caught():
             if p.is_alive():
                 p.terminate()
     assert torch.equal(got[0][1], got[1][1])                  # parameters were broadcast from rank 0 at construction
-    assert got[0][0] == "no error" and got[1][0] == "raised"
+    # BOTH ranks raise (the verdict is all-gathered): rank 0 must not carry on into a collective rank 1 never joins
+    assert got[0][0] == "raised" and got[1][0] == "raised"
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its two ranks itself (one process per GPU, as detectron2's launch does
+    at reference train_net.py:302-309) and rank 0's line says n_gpus 2 -- never a silent dp1 run."""
+    import json
+    r = _run_bench(["--gpus", "2", "--rendezvous-only"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["rendezvous_only"] is True
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    r = _run_bench(["--gpus", "8", "--rendezvous-only"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -54,6 +54,9 @@ class GradBuckets:
         self._calibrating = True
         self._layout(list(range(len(self.params))))
         self._works = []
+        # the 1 / world of the gradient mean rides in the collective where the backend can do it (RCCL: ncclAvg), so no
+        # separate pass over the flat buffer follows the last all-reduce; gloo (CPU tests, rehearsal) sums and scales
+        self._avg_in_collective = self.world > 1 and dist.get_backend(process_group) == "nccl"
         self._hooks = [p.register_post_accumulate_grad_hook(self._autograd_hook) for p in self.params]
         if listen_ops:
             from . import ops
@@ -119,7 +122,8 @@ class GradBuckets:
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 self.flat[s:e].copy_(host)
                 return
-            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+            self._works.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
 
     # ---- step protocol --------------------------------------------------------------------------
     def zero_grad(self):
@@ -151,7 +155,7 @@ class GradBuckets:
         for w in self._works:
             w.wait()
         self._works = []
-        if self.world > 1:
+        if self.world > 1 and not self._avg_in_collective:
             self.flat.mul_(1.0 / self.world)
         for i, v in self._views.items():         # the reduced buffer must be what the kernels accumulated into
             g = self.params[i].grad
@@ -167,10 +171,16 @@ class GradBuckets:
                 box = [(expected, order)]
                 dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                            group=self.group)
-                if box[0][0] != expected:
-                    bad = [i for i, (a, b) in enumerate(zip(box[0][0], expected)) if a != b]
-                    raise RuntimeError(f"GradBuckets: gradient contributions differ from rank 0 for parameters {bad[:8]} "
-                                       "(replicas must run the same graph)")
+                # the verdict is collective: every rank learns whether ANY rank diverged and all of them raise together -- a rank
+                # that carried on alone would block in its next all-reduce (RCCL has no timeout by default)
+                bad = [i for i, (a, b) in enumerate(zip(box[0][0], expected)) if a != b]
+                verdicts = [None] * self.world
+                dist.all_gather_object(verdicts, (dist.get_rank(self.group), bad[:8]), group=self.group)
+                diverged = [(r, b) for r, b in verdicts if b]
+                if diverged:
+                    raise RuntimeError("GradBuckets: gradient contributions differ from rank 0 on rank(s) "
+                                       + ", ".join(f"{r} (parameters {b})" for r, b in diverged)
+                                       + " -- replicas must run the same graph; every rank stops here")
                 expected, order = box[0]
             self._expected = expected
             active = [i for i in order if expected[i] > 0]
