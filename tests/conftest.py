@@ -49,6 +49,29 @@ def record_parity(test: str, **figures):
         ent[k] = float(v) if isinstance(v, (int, float, np.floating)) or (torch.is_tensor(v) and v.numel() == 1) else v
 
 
+MASK_ABS_TOL = 5e-2          # bf16 mode, abs error of the `pred_masks` logits
+
+
+def mask_band_figures(pred, ref, tol=MASK_ABS_TOL):
+    """Where the mask-sign disagreements sit, in the contract's own unit (`pred_masks` logits within 5e-2 ABS).
+    A mask pixel's sign is a thresholded logit: a product logit within `tol` of the reference's may legitimately land on the other
+    side of 0 iff |reference logit| <= tol.  Returns abs-error statistics, the number of sign flips, the share of them inside that
+    band, and the sign agreement over the pixels OUTSIDE the band (where no in-tolerance error can flip a sign)."""
+    p, r = pred.detach().double().cpu().reshape(-1), ref.detach().double().cpu().reshape(-1)
+    err = (p - r).abs()
+    flips = (p > 0) != (r > 0)
+    band = r.abs() <= tol
+    nflip = int(flips.sum())
+    outside = ~band
+    return {"abs_err_max": float(err.max()), "abs_err_mean": float(err.mean()), "abs_err_p999": float(err.kthvalue(max(1, int(0.999 * err.numel()))).values),
+            "ref_abs_mean": float(r.abs().mean()), "pixels": int(p.numel()), "sign_flips": nflip,
+            "mask_sign_agreement": 1.0 - nflip / p.numel(), "share_of_pixels_in_band": float(band.double().mean()),
+            "flips_inside_band_share": float((flips & band).sum()) / max(nflip, 1),
+            "flips_outside_band": int((flips & outside).sum()),
+            "sign_agreement_outside_band": 1.0 - float((flips & outside).sum()) / max(int(outside.sum()), 1),
+            "max_ref_abs_at_a_flip": float(r.abs()[flips].max()) if nflip else 0.0, "band_abs_tol": tol}
+
+
 def pytest_sessionfinish(session, exitstatus):
     if not _PARITY:
         return

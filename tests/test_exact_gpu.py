@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, record_parity
+from conftest import load_golden, mask_band_figures, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -203,6 +203,7 @@ def _decoder_figures(o, g):
     figs["mask_sign_agreement"] = float(((o["pred_masks"].cpu() > 0) == (g["pred_masks"] > 0)).float().mean())
     for i, a in enumerate(o["aux_outputs"]):
         figs[f"aux{i}_logits"] = rel(a["pred_logits"], g[f"aux{i}_logits"])
+    figs["mask_band"] = mask_band_figures(o["pred_masks"], g["pred_masks"])
     return figs
 
 
@@ -266,7 +267,8 @@ def test_full_model_free_running_forward_backward_exact(U):
             named = dict(model.named_parameters())
             figs = {"loss_rel": abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])),
                     "pred_logits": rel(out["pred_logits"], g["pred_logits"]), "pred_masks": rel(out["pred_masks"], g["pred_masks"]),
-                    "mask_sign_agreement": float(((out["pred_masks"].detach().cpu() > 0) == (g["pred_masks"] > 0)).float().mean())}
+                    "mask_sign_agreement": float(((out["pred_masks"].detach().cpu() > 0) == (g["pred_masks"] > 0)).float().mean()),
+                    "mask_band": mask_band_figures(out["pred_masks"], g["pred_masks"])}
             grads = {}
             for i, n in enumerate(g["grad_names"]):
                 n = str(n)
@@ -313,7 +315,9 @@ def test_full_size_swin_l_free_running_exact(U):
                 out, _ = model.forward_features(batch)
             res[mode] = {"pred_logits": rel(out["pred_logits"], oref["pred_logits"]), "pred_masks": rel(out["pred_masks"], oref["pred_masks"]),
                          "mask_sign_agreement": float(((out["pred_masks"].cpu() > 0) == (oref["pred_masks"] > 0)).float().mean()),
-                         "aux_logits": [rel(a["pred_logits"], b["pred_logits"]) for a, b in zip(out["aux_outputs"], oref["aux_outputs"])]}
+                         "aux_logits": [rel(a["pred_logits"], b["pred_logits"]) for a, b in zip(out["aux_outputs"], oref["aux_outputs"])],
+                         "mask_band": mask_band_figures(out["pred_masks"], oref["pred_masks"]),
+                         "aux_mask_band": [mask_band_figures(a["pred_masks"], b["pred_masks"]) for a, b in zip(out["aux_outputs"], oref["aux_outputs"])]}
             del model, out
             torch.cuda.empty_cache()
         finally:

@@ -35,9 +35,13 @@ for k, e0, e1 in recs:
     agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in agg.values())
 print(f"total gemm_nt time {tot:.2f} ms in {len(recs)} launches")
-print(f"{'M':>7} {'N':>5} {'K':>5} {'A':>8} epi {'out':>8} {'n':>4} {'ms':>7} {'us/launch':>9} {'TF/s':>7} {'GB/s':>7}")
-for k, (n, ms) in sorted(agg.items(), key=lambda x: -x[1][1])[:60]:
+# floors per launch: MFMA = 2MNK / 2.5 PFLOP/s (dense bf16 peak); HBM = algorithmic bytes / 6.3 TB/s (what MI355X_MICROARCH.md calls
+# achievable of the 8 TB/s); x = measured / max(floors): how far the shape is from whichever roof bounds it
+print(f"{'M':>7} {'N':>5} {'K':>5} {'A':>8} epi {'out':>8} {'n':>4} {'ms':>7} {'us/launch':>9} {'TF/s':>7} {'GB/s':>7} {'mfma_us':>8} {'hbm_us':>7} {'bound':>5} {'x':>5}")
+for k, (n, ms) in sorted(agg.items(), key=lambda x: -x[1][1])[:70]:
     M, N, Kd, ad, epi, od = k
     fl = 2.0 * M * N * Kd * n
     by = n * (M * Kd * (2 if ad == "bfloat16" else 4) + N * Kd * 2 + M * N * (2 if od == "bfloat16" else 4) + (M * N * 4 if epi == 3 else 0) + (M * N * 2 if epi in (1, 4, 5) else 0))
-    print(f"{M:7d} {N:5d} {Kd:5d} {ad:>8} {epi:3d} {od:>8} {n:4d} {ms:7.3f} {ms * 1e3 / n:9.1f} {fl / ms / 1e9:7.1f} {by / ms / 1e6:7.1f}")
+    us = ms * 1e3 / n
+    f_m, f_h = fl / n / 2.5e15 * 1e6, by / n / 6.3e12 * 1e6
+    print(f"{M:7d} {N:5d} {Kd:5d} {ad:>8} {epi:3d} {od:>8} {n:4d} {ms:7.3f} {us:9.1f} {fl / ms / 1e9:7.1f} {by / ms / 1e6:7.1f} {f_m:8.1f} {f_h:7.1f} {'mfma' if f_m > f_h else 'hbm':>5} {us / max(f_m, f_h):5.2f}")
