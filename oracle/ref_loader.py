@@ -260,3 +260,101 @@ def load_sequence():
     ns.geometry = _load("model.modeling.monodepth_loss", "modeling/monodepth_loss.py")
     ns.ShapeSpec = _ShapeSpec
     return ns
+
+
+def load_data_eval():
+    """The reference's evaluation loop, depth metrics, KITTI ground-truth projection and dataset registration, for the fixtures of
+    SURVEY.md §8f rank 4 (oracle/make_data_eval_golden.py).  Files executed: model/evaluation/evaluator.py,
+    model/evaluation/kitti_evaluation.py, model/data/datasets/register_cityscapes_panoptic.py, model/data/datasets/register_kitti.py,
+    model/modeling/monodepth_loss.py (for disp_to_depth).  Stand-ins for what they import and the image lacks -- documented
+    semantics only: detectron2.utils.comm (single process), detectron2.utils.logger.log_every_n_seconds (a plain log call),
+    detectron2.data.{DatasetCatalog, MetadataCatalog} (name -> function / attribute bag), detectron2.utils.file_io.PathManager
+    (os / open), detectron2.data.datasets.builtin_meta.CITYSCAPES_CATEGORIES (the public 19-class label table [not in reference]),
+    detectron2.utils.events.get_event_storage (raises, as outside a trainer); cv2 / matplotlib.cm / skimage are imported by
+    kitti_evaluation.py at module level but not touched by the functions called here: empty name holders.  numpy 2 removed the
+    `np.int` alias the reference's generate_depth_map uses (kitti_evaluation.py:152): restored as `int` while the fixture is made."""
+    assert available(), "reference tree not present"
+    _install_stubs()
+    import logging
+    import numpy as np
+
+    class _Comm:
+        get_world_size = staticmethod(lambda: 1)
+        get_local_size = staticmethod(lambda: 1)
+        get_rank = staticmethod(lambda: 0)
+        is_main_process = staticmethod(lambda: True)
+        synchronize = staticmethod(lambda: None)
+        all_gather = staticmethod(lambda x: [x])
+
+    comm = _mod("detectron2.utils.comm", **{k: getattr(_Comm, k) for k in ("get_world_size", "get_local_size", "get_rank", "is_main_process", "synchronize", "all_gather")})
+    sys.modules["detectron2.utils"].comm = comm
+
+    def log_every_n_seconds(lvl, msg, n=1, *, name=None):
+        logging.getLogger(name or "model.evaluation.evaluator").log(lvl, msg)
+    _mod("detectron2.utils.logger", log_every_n_seconds=log_every_n_seconds)
+
+    class _Meta:
+        def __init__(self, name):
+            self.name = name
+
+        def set(self, **kw):
+            self.__dict__.update(kw)
+            return self
+
+    class _MetaCat(dict):
+        def get(self, name):
+            return self.setdefault(name, _Meta(name))
+
+    class _DataCat(dict):
+        def list(self):
+            return list(self.keys())
+
+        def remove(self, name):
+            self.pop(name)
+
+        def register(self, name, func):
+            self[name] = func
+
+        def get(self, name):
+            return self[name]()
+
+    class _PathManager:
+        ls = staticmethod(lambda d: sorted(os.listdir(d)))
+        isfile = staticmethod(os.path.isfile)
+        open = staticmethod(open)
+
+    from uenc.datasets import CITYSCAPES_CATEGORIES     # the public label table (detectron2 builtin_meta) -- not reference content
+    ns = types.SimpleNamespace(DatasetCatalog=_DataCat(), MetadataCatalog=_MetaCat())
+    _mod("detectron2.data", DatasetCatalog=ns.DatasetCatalog, MetadataCatalog=ns.MetadataCatalog)
+    _mod("detectron2.data.datasets")
+    _mod("detectron2.data.datasets.builtin_meta", CITYSCAPES_CATEGORIES=CITYSCAPES_CATEGORIES)
+    _mod("detectron2.utils.file_io", PathManager=_PathManager)
+
+    def get_event_storage():
+        raise AssertionError("get_event_storage() has to be called inside a 'with EventStorage(...)' context!")
+    _mod("detectron2.utils.events", get_event_storage=get_event_storage)
+    for name in ("cv2", "skimage", "matplotlib"):
+        if name not in sys.modules:
+            _mod(name)
+    if "matplotlib.cm" not in sys.modules:
+        sys.modules["matplotlib"].cm = _mod("matplotlib.cm")
+    if not hasattr(np, "int"):
+        np.int = int
+    base = os.path.join(REF_ROOT, "model")
+    for name, sub in [("model.evaluation", "evaluation"), ("model.data", "data"), ("model.data.datasets", "data/datasets"), ("model.utils", "utils")]:
+        m = sys.modules.get(name)
+        if m is None or not getattr(m, "__path__", None) or getattr(m, "__file__", None):
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(base, sub)]
+            sys.modules[name] = m
+    if "model.utils.misc" not in sys.modules:
+        _mod("model.utils.misc", is_dist_avail_and_initialized=lambda: False)
+    m = sys.modules.get("model.modeling.monodepth_loss")
+    if m is not None and getattr(m, "__file__", None) is None:
+        del sys.modules["model.modeling.monodepth_loss"]
+    ns.geometry = _load("model.modeling.monodepth_loss", "modeling/monodepth_loss.py")
+    ns.evaluator = _load("model.evaluation.evaluator", "evaluation/evaluator.py")
+    ns.kitti_eval = _load("model.evaluation.kitti_evaluation", "evaluation/kitti_evaluation.py")
+    ns.reg_cityscapes = _load("model.data.datasets.register_cityscapes_panoptic", "data/datasets/register_cityscapes_panoptic.py")
+    ns.reg_kitti = _load("model.data.datasets.register_kitti", "data/datasets/register_kitti.py")
+    return ns

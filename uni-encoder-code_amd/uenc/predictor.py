@@ -56,8 +56,4 @@ class DefaultPredictor:
 SEQUENCE_SIZE = (192, 512)            # demo/defaults.py:84-86
 
 
-def disp_to_depth(disp, min_depth=0.1, max_depth=100.0):
-    """sigmoid disparity -> (scaled disparity, depth), reference model/modeling/monodepth_loss.py:103-112."""
-    min_disp, max_disp = 1 / max_depth, 1 / min_depth
-    scaled = min_disp + (max_disp - min_disp) * disp
-    return scaled, 1 / scaled
+from .evaluation import disp_to_depth  # noqa: E402,F401  (reference model/modeling/monodepth_loss.py:103-112)
