@@ -325,3 +325,14 @@ def test_full_size_swin_l_free_running_exact(U):
     record_parity("free_running/swin_l_1024x2048_one_image", exact=res["exact"], bf16=res["bf16"])
     e = res["exact"]
     assert e["pred_logits"] < 1e-3 and e["pred_masks"] < 1e-3 and e["mask_sign_agreement"] >= 0.999, e
+    assert e["mask_band"]["flips_outside_band"] == 0 and e["mask_band"]["abs_err_max"] < 5e-2, e["mask_band"]      # the contract's abs unit, fp32 mode
+    # Product (bf16) mode, measured in the contract's units (logits <= 2e-2 rel, masks <= 5e-2 abs, sign >= 99.9 %).
+    # The logits bound holds; the mask bounds do NOT (round 3 measurement, profiles/r03_parity_error_sources.json): mean abs error 0.051,
+    # sign agreement 99.72 %, 71 % of the flips inside the +-5e-2 band, 99.92 % agreement outside it.  The error is the accumulated
+    # operand rounding of all three stages (backbone alone -> 99.80 %, + pixel decoder -> 99.86 %, all fp32 -> 99.9999 %); the
+    # thresholded mask path alone in fp32 buys 0.06 points.  The asserts pin the measured level so that it cannot degrade silently.
+    b = res["bf16"]
+    assert b["pred_logits"] < 2e-2, b["pred_logits"]
+    mb = b["mask_band"]
+    assert mb["abs_err_mean"] < 7e-2 and mb["mask_sign_agreement"] > 0.996 and mb["sign_agreement_outside_band"] > 0.9985 and \
+        mb["flips_inside_band_share"] > 0.6 and mb["max_ref_abs_at_a_flip"] < 0.5, mb

@@ -196,7 +196,7 @@ def test_transformer_decoder_golden(U):
                   pred_masks=rel(o["pred_masks"], g["pred_masks"]), mask_sign_agreement=sign,
                   envelope_pred_logits=rel(env["pred_logits"], g["pred_logits"]), envelope_pred_masks=rel(env["pred_masks"], g["pred_masks"]),
                   envelope_mask_sign_agreement=env_sign)
-    assert sign > env_sign - 0.02 and sign > 0.95, (sign, env_sign)
+    assert sign > env_sign - 0.02 and sign > 0.97, (sign, env_sign)          # measured 97.5 % (envelope 96.8 %)
 
 
 def test_full_model_forward_backward_golden(U):
@@ -230,8 +230,9 @@ def test_full_model_forward_backward_golden(U):
     record_parity("bf16/small_full_model_free_running", loss=float(loss), loss_reference=float(g["loss"]),
                   pred_logits=rel(out["pred_logits"], g["pred_logits"]), pred_masks=rel(out["pred_masks"], g["pred_masks"]))
     assert abs(float(loss) - float(g["loss"])) < 5e-2 * abs(float(g["loss"]))
-    assert rel(out["pred_logits"], g["pred_logits"]) < 0.15
-    assert rel(out["pred_masks"], g["pred_masks"]) < 0.15
+    # (measured 7.0e-2 / 6.2e-2: the forward has no atomics, so these figures are the same on every box)
+    assert rel(out["pred_logits"], g["pred_logits"]) < 0.09
+    assert rel(out["pred_masks"], g["pred_masks"]) < 0.08
     # gradients: pin the (detached, boolean) attention masks to the fp32 oracle's so that the comparison measures
     # the differentiable arithmetic; the reference's gradient does not flow through the masks either (:511)
     from oracle import fill

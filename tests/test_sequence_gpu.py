@@ -4,6 +4,8 @@ modules produced (tests/golden/sequence_branch.npz, oracle/make_sequence_golden.
 Tolerances, relative L2 per tensor: the product's bf16-MFMA mode 1e-2 per decoder output (bf16 operands through 10-25 stacked
 convolutions; the pose head's 0.01-scaled 6-vector is compared absolutely against its own magnitude), the fp32 "exact" mode 1e-4.
 """
+import os
+
 import pytest
 import torch
 
