@@ -22,6 +22,16 @@ for (name, lo), (_, hi) in zip(marks, marks[1:]):
     b = sum(e - s for s, e, n in seg if lo <= (s - t0) / 1e6 < hi) / 1e6
     c = sum(1 for s, e, n in seg if lo <= (s - t0) / 1e6 < hi)
     print(f"  {name:36s} wall {min(hi, wall) - lo:7.2f} ms  busy {b:7.2f} ms  launches {c:5d}")
+import os
+if os.environ.get("PHASE_DETAIL"):
+    for (name, lo), (_, hi) in zip(marks, marks[1:]):
+        pt, pc = collections.Counter(), collections.Counter()
+        for s, e, n in seg:
+            if lo <= (s - t0) / 1e6 < hi:
+                pt[n] += e - s; pc[n] += 1
+        print(f"---- {name}")
+        for n, t in pt.most_common(int(os.environ["PHASE_DETAIL"])):
+            print(f"   {t / 1e6:8.3f} {pc[n]:5d}  {n}")
 tot, cnt = collections.Counter(), collections.Counter()
 for s, e, n in seg:
     tot[n] += e - s; cnt[n] += 1

@@ -420,6 +420,213 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n) {
     else __builtin_amdgcn_s_waitcnt(0x0f70);
 }
 
+// ---- register-direct epilogue (bf16 results) of the large-tile NT kernels: the wave owns the 128 x 64 patch at (mbase, nbase) ----
+// ---- register-direct epilogue (bf16 results) ----
+// acc[i][j][r] = C[m0 + wm*128 + j*16 + fr][n0 + wn*64 + i*16 + 4*fg + r]: a lane owns 4 consecutive columns of one row per
+// (i, j) and the four lanes fr, fr+16, fr+32, fr+48 own 16 consecutive ones.  The 8-byte bf16 pieces are widened first: one
+// v_permlane16_swap between the lanes 16 apart trades the second half of column group i against the first half of group
+// i+1, after which a lane holds 8 consecutive columns = one 16-byte store, in 64-byte runs per row; the saved bf16
+// activation of the dGELU / dReLU epilogues is read the same way.  No LDS, no barriers: the LDS-staged form below takes 6 us
+// of a 27 us K = 768 tile (four passes, eight barriers, half the waves idle in each); measured on the workload's shapes the
+// direct form is 5-13 % faster per launch for bf16 results.  fp32 results keep the staged form: its 1 KB runs per row beat
+// 64-byte (direct) and 256-byte (per-wave patches) runs by 7-20 % on the HBM-bound shapes.  Bit 32768 of UENC_GEMM_VARIANT
+// selects the staged form everywhere (A/B).
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)[4][8], int mbase, int nbase, int fr, int fg, bool lead) {
+    const int mrow = mbase + fr, ncol = nbase + 4 * fg;
+    float bv4[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = ncol + i * 16;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias != nullptr && n < p.N && lead) b = *(const float4*)(p.bias + n);
+        bv4[i][0] = b.x; bv4[i][1] = b.y; bv4[i][2] = b.z; bv4[i][3] = b.w;
+    }
+    // column at which this lane's 16-byte bf16 store of pair pr (column groups 2 pr, 2 pr + 1) starts
+    const int odd = fg & 1;
+    const int n16[2] = {nbase + (0 + odd) * 16 + 4 * (fg - odd), nbase + (2 + odd) * 16 + 4 * (fg - odd)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = mrow + j * 16;
+        const bool row_ok = m < p.M;
+        float v[4][4];
+        const float al = nt_alpha(p, min(m, p.M - 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i][r] = (acc[i][j][r] + bv4[i][r]) * al;
+        u32x2 pre2[4];
+        if (EPI == EPI_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4 q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q[r] = (bf16)v[i][r]; v[i][r] = gelu_f(v[i][r]); }
+                pre2[i] = *(const u32x2*)&q;
+            }
+        } else if (EPI == EPI_RELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(v[i][r], 0.f);
+        } else if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = ncol + i * 16;
+                if (row_ok && n < p.N) {
+                    const float4 r0 = *(const float4*)((const float*)p.aux + (long)m * p.ldaux + n);
+                    v[i][0] += r0.x; v[i][1] += r0.y; v[i][2] += r0.z; v[i][3] += r0.w;
+                }
+            }
+        } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
+            // the saved bf16 activation is read in the widened layout (16 bytes per lane) and brought back to the accumulator
+            // layout by the same swap (an involution)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                u32x4 x = {0u, 0u, 0u, 0u};
+                if (row_ok && n16[pr] < p.N) x = *(const u32x4*)((const bf16*)p.aux + (long)m * p.ldaux + n16[pr]);
+                const u32x2 lo = __builtin_amdgcn_permlane16_swap(x[0], x[2], false, false);
+                const u32x2 hi = __builtin_amdgcn_permlane16_swap(x[1], x[3], false, false);
+                const u32x2 sa = {lo[0], hi[0]}, sb = {lo[1], hi[1]};
+                const bf16x4 s0 = *(const bf16x4*)&sa, s1 = *(const bf16x4*)&sb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[2 * pr][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr][r] * dgelu_f((float)s0[r]) : (((float)s0[r] > 0.f) ? v[2 * pr][r] : 0.f);
+                    v[2 * pr + 1][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr + 1][r] * dgelu_f((float)s1[r]) : (((float)s1[r] > 0.f) ? v[2 * pr + 1][r] : 0.f);
+                }
+            }
+        }
+        {
+            u32x2 o2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4 q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q[r] = (bf16)v[i][r];
+                o2[i] = *(const u32x2*)&q;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const u32x2 lo = __builtin_amdgcn_permlane16_swap(o2[2 * pr][0], o2[2 * pr + 1][0], false, false);
+                const u32x2 hi = __builtin_amdgcn_permlane16_swap(o2[2 * pr][1], o2[2 * pr + 1][1], false, false);
+                if (row_ok && n16[pr] < p.N) *(u32x4*)((bf16*)p.C + (long)m * p.ldc + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+            }
+        }
+        if (EPI == EPI_GELU && p.aux_out != nullptr) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const u32x2 lo = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][0], pre2[2 * pr + 1][0], false, false);
+                const u32x2 hi = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][1], pre2[2 * pr + 1][1], false, false);
+                if (row_ok && n16[pr] < p.N) *(u32x4*)(p.aux_out + (long)m * p.ldaux_out + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+            }
+        }
+    }
+}
+
+// ---- LDS-staged epilogue (fp32 results; bf16 under UENC_GEMM_VARIANT bit 32768): passes of 64 rows through a padded fp32 tile [64][260]
+// in LDS, then 8 consecutive columns per thread: 1 KB runs per row.  NWM = row groups of 128 the workgroup owns (wave group wm each). ----
+template <int EPI, int OUT_F32, int NTHREADS, int NWM>
+__device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)[4][8], unsigned char* smem, int m0, int n0, int wm, int wn,
+                                                   int t, int fr, int fg, bool lead, bool skip_stores) {
+    float* T = (float*)smem;
+    constexpr int LDT = 260;
+    const int erow = t >> 5, ecol = (t & 31) * 8;
+    constexpr int RPI = NTHREADS / 32;            // rows one iteration of the workgroup covers
+    const int n = n0 + ecol;
+    const bool ncol_ok = n < p.N;
+    const bool full8 = (n + 8 <= p.N);
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && ncol_ok && lead) {
+        const float4 b0 = *(const float4*)(p.bias + n);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2 * NWM; ++ps) {      // unrolled: acc[][] must keep compile-time indices (else it lives in scratch)
+        __syncthreads();
+        if (wm == (ps >> 1)) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = (ps & 1) * 4 + jj;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(f32x4*)(T + (jj * 16 + fr) * LDT + wn * 64 + i * 16 + 4 * fg) = acc[i][j];
+            }
+        }
+        __syncthreads();
+        if (!ncol_ok) continue;
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int rl = it * RPI + erow;
+            const int m = m0 + ps * 64 + rl;
+            if (m >= p.M) continue;
+            const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
+            float v[8];
+            const float al = nt_alpha(p, m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * al; v[4 + r] = (a1[r] + bv[4 + r]) * al; }
+            if (skip_stores) {
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) asm volatile("" :: "v"(v[r]));
+                continue;
+            }
+            if (EPI == EPI_GELU) {
+                if (p.aux_out != nullptr) {
+                    bf16x8 pre;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pre[r] = (bf16)v[r];
+                    bf16* dst = p.aux_out + (long)m * p.ldaux_out + n;
+                    if (full8) *(bf16x8*)dst = pre;
+                    else { bf16x4 q4; q4[0] = pre[0]; q4[1] = pre[1]; q4[2] = pre[2]; q4[3] = pre[3]; *(bf16x4*)dst = q4; }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+            } else if (EPI == EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (EPI == EPI_RESIDUAL) {
+                const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                const float4 r0 = *(const float4*)rp;
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
+            } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
+                const bf16* ap = (const bf16*)p.aux + (long)m * p.ldaux + n;
+                bf16x8 sv;
+                if (full8) sv = *(const bf16x8*)ap;
+                else {
+                    const bf16x4 q4 = *(const bf16x4*)ap;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sv[r] = q4[r]; sv[4 + r] = (bf16)0.f; }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    v[r] = (EPI == EPI_MUL_DGELU) ? v[r] * dgelu_f((float)sv[r]) : (((float)sv[r] > 0.f) ? v[r] : 0.f);
+            }
+            if (OUT_F32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                if (EPI == EPI_NONE && p.atomic) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (r < 4 || full8) atomicAdd(c + r, v[r]);
+                } else {
+                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                    if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                bf16* c = (bf16*)p.C + (long)m * p.ldc + n;
+                if (full8) *(bf16x8*)c = o;
+                else { bf16x4 q4; q4[0] = o[0]; q4[1] = o[1]; q4[2] = o[2]; q4[3] = o[3]; *(bf16x4*)c = q4; }
+            }
+        }
+    }
+}
+
 template <int EPI, int OUT_F32, int PIPE>
 __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (A 32 KB + W 32 KB)
@@ -652,209 +859,126 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
         continue;
     }
     if (!OUT_F32 && !(p.variant & 32768)) {
-        // ---- register-direct epilogue (bf16 results) ----
-        // acc[i][j][r] = C[m0 + wm*128 + j*16 + fr][n0 + wn*64 + i*16 + 4*fg + r]: a lane owns 4 consecutive columns of one row per
-        // (i, j) and the four lanes fr, fr+16, fr+32, fr+48 own 16 consecutive ones.  The 8-byte bf16 pieces are widened first: one
-        // v_permlane16_swap between the lanes 16 apart trades the second half of column group i against the first half of group
-        // i+1, after which a lane holds 8 consecutive columns = one 16-byte store, in 64-byte runs per row; the saved bf16
-        // activation of the dGELU / dReLU epilogues is read the same way.  No LDS, no barriers: the LDS-staged form below takes 6 us
-        // of a 27 us K = 768 tile (four passes, eight barriers, half the waves idle in each); measured on the workload's shapes the
-        // direct form is 5-13 % faster per launch for bf16 results.  fp32 results keep the staged form: its 1 KB runs per row beat
-        // 64-byte (direct) and 256-byte (per-wave patches) runs by 7-20 % on the HBM-bound shapes.  Bit 32768 of UENC_GEMM_VARIANT
-        // selects the staged form everywhere (A/B).
-        const int mrow = m0 + wm * 128 + fr, ncol = n0 + wn * 64 + 4 * fg;
-        float bv4[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = ncol + i * 16;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias != nullptr && n < p.N && blockIdx.y == 0) b = *(const float4*)(p.bias + n);
-            bv4[i][0] = b.x; bv4[i][1] = b.y; bv4[i][2] = b.z; bv4[i][3] = b.w;
-        }
-        // column at which this lane's 16-byte bf16 store of pair pr (column groups 2 pr, 2 pr + 1) starts
-        const int odd = fg & 1;
-        const int n16[2] = {n0 + wn * 64 + (0 + odd) * 16 + 4 * (fg - odd), n0 + wn * 64 + (2 + odd) * 16 + 4 * (fg - odd)};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = mrow + j * 16;
-            const bool row_ok = m < p.M;
-            float v[4][4];
-            const float al = nt_alpha(p, min(m, p.M - 1));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] = (acc[i][j][r] + bv4[i][r]) * al;
-            u32x2 pre2[4];
-            if (EPI == EPI_GELU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bf16x4 q;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { q[r] = (bf16)v[i][r]; v[i][r] = gelu_f(v[i][r]); }
-                    pre2[i] = *(const u32x2*)&q;
-                }
-            } else if (EPI == EPI_RELU) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(v[i][r], 0.f);
-            } else if (EPI == EPI_RESIDUAL) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = ncol + i * 16;
-                    if (row_ok && n < p.N) {
-                        const float4 r0 = *(const float4*)((const float*)p.aux + (long)m * p.ldaux + n);
-                        v[i][0] += r0.x; v[i][1] += r0.y; v[i][2] += r0.z; v[i][3] += r0.w;
-                    }
-                }
-            } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
-                // the saved bf16 activation is read in the widened layout (16 bytes per lane) and brought back to the accumulator
-                // layout by the same swap (an involution)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    u32x4 x = {0u, 0u, 0u, 0u};
-                    if (row_ok && n16[pr] < p.N) x = *(const u32x4*)((const bf16*)p.aux + (long)m * p.ldaux + n16[pr]);
-                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(x[0], x[2], false, false);
-                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(x[1], x[3], false, false);
-                    const u32x2 sa = {lo[0], hi[0]}, sb = {lo[1], hi[1]};
-                    const bf16x4 s0 = *(const bf16x4*)&sa, s1 = *(const bf16x4*)&sb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[2 * pr][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr][r] * dgelu_f((float)s0[r]) : (((float)s0[r] > 0.f) ? v[2 * pr][r] : 0.f);
-                        v[2 * pr + 1][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr + 1][r] * dgelu_f((float)s1[r]) : (((float)s1[r] > 0.f) ? v[2 * pr + 1][r] : 0.f);
-                    }
-                }
-            }
-            {
-                u32x2 o2[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bf16x4 q;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) q[r] = (bf16)v[i][r];
-                    o2[i] = *(const u32x2*)&q;
-                }
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(o2[2 * pr][0], o2[2 * pr + 1][0], false, false);
-                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(o2[2 * pr][1], o2[2 * pr + 1][1], false, false);
-                    if (row_ok && n16[pr] < p.N) *(u32x4*)((bf16*)p.C + (long)m * p.ldc + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
-                }
-            }
-            if (EPI == EPI_GELU && p.aux_out != nullptr) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const u32x2 lo = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][0], pre2[2 * pr + 1][0], false, false);
-                    const u32x2 hi = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][1], pre2[2 * pr + 1][1], false, false);
-                    if (row_ok && n16[pr] < p.N) *(u32x4*)(p.aux_out + (long)m * p.ldaux_out + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
-                }
-            }
-        }
+        nt_epilogue_direct<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, fr, fg, blockIdx.y == 0);
         if (!has_next) return;
         pos = pos_next;
         continue;
     }
-    const bool skip_stores = (p.variant & 8192) != 0;      // timing experiment: epilogue math + LDS passes, no global stores / aux loads
-    float* T = (float*)smem;
-    constexpr int LDT = 260;
-    const int erow = t >> 5, ecol = (t & 31) * 8;
-    const int n = n0 + ecol;
-    const bool ncol_ok = n < p.N;
-    const bool full8 = (n + 8 <= p.N);
-    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && ncol_ok && blockIdx.y == 0) {
-        const float4 b0 = *(const float4*)(p.bias + n);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
-        if (full8) { const float4 b1 = *(const float4*)(p.bias + n + 4); bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
-    }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {      // unrolled: acc[][] must keep compile-time indices (else it lives in scratch)
-        __syncthreads();
-        if (wm == (ps >> 1)) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = (ps & 1) * 4 + jj;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *(f32x4*)(T + (jj * 16 + fr) * LDT + wn * 64 + i * 16 + 4 * fg) = acc[i][j];
-            }
-        }
-        __syncthreads();
-        if (!ncol_ok) continue;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rl = it * 16 + erow;
-            const int m = m0 + ps * 64 + rl;
-            if (m >= p.M) continue;
-            const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
-            float v[8];
-            const float al = nt_alpha(p, m);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * al; v[4 + r] = (a1[r] + bv[4 + r]) * al; }
-            if (skip_stores) {
-                if (EPI == EPI_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) asm volatile("" :: "v"(v[r]));
-                continue;
-            }
-            if (EPI == EPI_GELU) {
-                if (p.aux_out != nullptr) {
-                    bf16x8 pre;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) pre[r] = (bf16)v[r];
-                    bf16* dst = p.aux_out + (long)m * p.ldaux_out + n;
-                    if (full8) *(bf16x8*)dst = pre;
-                    else { bf16x4 q4; q4[0] = pre[0]; q4[1] = pre[1]; q4[2] = pre[2]; q4[3] = pre[3]; *(bf16x4*)dst = q4; }
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
-            } else if (EPI == EPI_RELU) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (EPI == EPI_RESIDUAL) {
-                const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
-                const float4 r0 = *(const float4*)rp;
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
-            } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
-                const bf16* ap = (const bf16*)p.aux + (long)m * p.ldaux + n;
-                bf16x8 sv;
-                if (full8) sv = *(const bf16x8*)ap;
-                else {
-                    const bf16x4 q4 = *(const bf16x4*)ap;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { sv[r] = q4[r]; sv[4 + r] = (bf16)0.f; }
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    v[r] = (EPI == EPI_MUL_DGELU) ? v[r] * dgelu_f((float)sv[r]) : (((float)sv[r] > 0.f) ? v[r] : 0.f);
-            }
-            if (OUT_F32) {
-                float* c = (float*)p.C + (long)m * p.ldc + n;
-                if (EPI == EPI_NONE && p.atomic) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        if (r < 4 || full8) atomicAdd(c + r, v[r]);
-                } else {
-                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-                    if (full8) *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-            } else {
-                bf16x8 o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
-                bf16* c = (bf16*)p.C + (long)m * p.ldc + n;
-                if (full8) *(bf16x8*)c = o;
-                else { bf16x4 q4; q4[0] = o[0]; q4[1] = o[1]; q4[2] = o[2]; q4[3] = o[3]; *(bf16x4*)c = q4; }
-            }
-        }
-    }
+    nt_epilogue_staged<EPI, OUT_F32, T2, 2>(p, acc, smem, m0, n0, wm, wn, t, fr, fg, blockIdx.y == 0, (p.variant & 8192) != 0);
     if (!has_next) return;
     __syncthreads();          // the staged epilogue's last reads of the LDS tile precede the next tile's DMA writes
     pos = pos_next;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Half-height variant with TWO workgroups per CU: 128 x 256 x 32 tile, 4 waves (1 x 4), each wave the same 128(m) x 64(n) patch of
+// 8 x 4 MFMA tiles as in the 256-tile kernel, 72 KB of LDS (ring of three 24 KB k-steps: A 128 rows + W 256 rows of 64 bytes).
+// Why: the 256-tile kernel owns its CU alone, and vector-memory operations of a wave retire in order -- a tile's result stores sit
+// in front of the next tile's operand DMA in the same queue, so a CU alternates between "MFMA" and "drain stores / wait for loads".
+// On the shapes whose epilogue moves as many bytes as the main loop computes (K <= 384, fp32 residual / saved-activation epilogues,
+// N >= 2304 with GELU) that serialisation is 30-50 % of the launch (profiles/r03_gemm_decompose.txt).  Two independent workgroups per
+// CU have independent queues: one's epilogue stores and prologue loads run under the other's MFMAs, and the workgroup scheduler,
+// not a persistent loop, refills a slot as soon as a tile retires.  Price: A and W panels travel L2 -> LDS 1.5 x as often per flop.
+//   main loop, per 32-wide k-step s:   vmcnt(6): step s has landed (step s + 1 stays in flight) | s_barrier (everyone's step s is in LDS,
+//   everyone has finished reading step s - 1) | DMA of step s + 2 into the buffer step s - 1 used | 12 ds_read_b128 | 32 MFMAs
+// LDS rows are 64 bytes (four 16-byte chunks); chunk c of row r lives at slot c ^ perm[(r >> 2) & 3], perm = {0, 3, 2, 1}: the
+// 16-lane groups a ds_read_b128 is serviced in ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md §LDS) then cover all 64 banks once.
+// As in the 256-tile kernel the swizzle is applied to the per-lane SOURCE address of the lane-linear LDS-DMA.
+// ---------------------------------------------------------------------------------------------
+#define BM3 128
+#define BN3 256
+#define BK3 32
+#define T3 256
+#define STAGE3 ((BM3 + BN3) * BK3 * 2)      // 24576 bytes
+
+__device__ __forceinline__ int lds_off32(int row, int chunk) {
+    const int f = (4 - ((row >> 2) & 3)) & 3;                  // perm {0, 3, 2, 1}
+    return row * 64 + ((chunk ^ f) << 4);
+}
+
+template <int EPI, int OUT_F32>
+__global__ __launch_bounds__(T3, 2) void gemm_nt128_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 3 x (A 8 KB + W 16 KB)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wn = wave;
+    const int ntiles_all = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, ntiles_all);
+    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    const int m0 = mt * BM3, n0 = nt * BN3;
+    const int nks = p.K / BK3;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int fr = lane & 15, fg = lane >> 4;
+    // DMA geometry: instruction q of a thread fills LDS chunk L = q * 256 + t of an image (row L >> 2, slot L & 3)
+    const bf16* asrc[2];
+    const bf16* wsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int L = q * T3 + t, row = L >> 2, slot = L & 3;
+        const int chunk = slot ^ ((4 - ((row >> 2) & 3)) & 3);
+        if (q < 2) asrc[q] = (const bf16*)p.A + (long)min(m0 + row, p.M - 1) * p.lda + chunk * 8;
+        wsrc[q] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + chunk * 8;
+    }
+    auto issue = [&](int ks, int buf) {
+        unsigned char* As = smem + buf * STAGE3 + wave * 1024;
+        unsigned char* Ws = As + BM3 * BK3 * 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) __builtin_amdgcn_global_load_lds(asrc[q] + (long)ks * BK3, (lds_void*)(As + q * 4096), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(wsrc[q] + (long)ks * BK3, (lds_void*)(Ws + q * 4096), 16, 0, 0);
+    };
+    issue(0, 0);
+    if (nks > 1) issue(1, 1);
+    const int aoff = lds_off32(fr, fg), boff = lds_off32(wn * 64 + fr, fg);       // row + 16 j keeps (row >> 2) & 3 -> + 1024 j
+    int buf = 0;
+    for (int s = 0; s < nks; ++s) {
+        if (s + 1 < nks) __builtin_amdgcn_s_waitcnt(0x0f76);      // vmcnt(6): step s landed, step s + 1 in flight
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nks) issue(s + 2, buf == 0 ? 2 : buf - 1);
+        const unsigned char* As = smem + buf * STAGE3;
+        const unsigned char* Ws = As + BM3 * BK3 * 2;
+        bf16x8 wf[4], xf[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(Ws + i * 1024 + boff);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(As + j * 1024 + aoff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (!OUT_F32 && !(p.variant & 32768)) {
+        nt_epilogue_direct<EPI>(p, acc, m0, n0 + wn * 64, fr, fg, true);
+        return;
+    }
+    __syncthreads();          // the staged epilogue reuses the ring
+    nt_epilogue_staged<EPI, OUT_F32, T3, 1>(p, acc, smem, m0, n0, 0, wn, t, fr, fg, true, false);
+}
+
+template <int EPI, int OUT_F32>
+static int launch_nt128(GemmNT& p, hipStream_t stream) {
+    p.tiles_m = (p.M + BM3 - 1) / BM3; p.tiles_n = (p.N + BN3 - 1) / BN3;
+    static bool attr_set = false;      // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt128_kernel<EPI, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    p.persist = 0;
+    hipLaunchKernelGGL((gemm_nt128_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n), dim3(T3), 3 * STAGE3, stream, p);
+    return UENC_OK;
 }
 
 template <int EPI, int OUT_F32, int PIPE>
@@ -877,6 +1001,20 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
     p.persist = (PIPE == 1 && p.splits == 1 && ntiles > ncu && !(p.variant & 65536)) ? 1 : 0;
     hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE>), dim3(p.persist ? ncu : ntiles, p.splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
+}
+
+// Which of the two large-tile kernels takes a shape (both compute the same sums in the same k order: identical results).
+// UENC_GEMM_VARIANT bit 131072 forces the two-workgroups-per-CU kernel, bit 262144 the one-workgroup kernel (A/B).
+static bool nt128_wins(int M, int N, int K, int epilogue, int c_dtype, int variant) {
+    if (variant & 262144) return false;
+    if (variant & 131072) return true;
+    // Measured per workload shape (tools/gemm_nt128_ab.py -> profiles/r03_gemm_nt128_ab.txt): the half-height kernel wins 3-15 % where a
+    // single 256-wide column of tiles covers N and the contraction is short (the deformable encoder's K = 256 projections and its
+    // 1024 -> 256 FFN GEMM with the fp32 residual epilogue, the decoder's key / value projections over the 1/4-resolution map): every
+    // A row is read once and the launch is store-bound.  Everywhere else its 1.5 x L2 -> LDS traffic and 1.5 x DMA instructions per
+    // MFMA cost 4-30 %.
+    (void)M; (void)epilogue; (void)c_dtype;
+    return N > 192 && N <= 288 && K <= 1024;
 }
 
 static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
@@ -969,9 +1107,10 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         if (prof) uenc_prof_end(stream);
         UENC_LAUNCH_RET();
     }
+    const bool half_tile = big && !p.atomic && !partials && (K % BK3 == 0) && nt128_wins(M, N, K, epilogue, c_dtype, p.variant);
     if (big) {
         int rc = UENC_EINVAL;
-#define LAUNCH2(E, F) rc = (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
+#define LAUNCH2(E, F) rc = half_tile ? launch_nt128<E, F>(p, stream) : (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
         if (c_dtype == UENC_F32) {
             if (epilogue == EPI_NONE) LAUNCH2(EPI_NONE, 1);
             else if (epilogue == EPI_RESIDUAL) LAUNCH2(EPI_RESIDUAL, 1);
