@@ -332,7 +332,15 @@ def main():
     local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    force_coll = world == 1 and os.environ.get("UENC_DP_FORCE_COLLECTIVE") == "1"      # one-GPU rehearsal of the RCCL call path (uenc/dp.py)
+    if force_coll:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            free_port = so.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_coll:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("UENC_DIST_BACKEND", "nccl")      # "gloo": functional rehearsal of N ranks on fewer GPUs
         if backend == "nccl":
@@ -370,7 +378,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -400,7 +408,7 @@ def main():
         step()
     sync()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
@@ -502,6 +510,9 @@ def main():
                                       for k, v in fams.items()}},
             "loss": round(loss_val, 5),
         }
+        if force_coll:
+            rec["config"]["rccl_rehearsal"] = ("UENC_DP_FORCE_COLLECTIVE=1: every gradient bucket went through an RCCL all-reduce (ncclAvg, async) "
+                                               "in a world of one rank -- the N > 1 call path on one GPU; not a scaling figure")
         if swin:
             rec["config"]["model_tflop_per_step_per_gpu"] = round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3, 2)
             rec["model_tflops_per_gpu"] = round(3 * GFLOP_FWD_PER_IMG * PER_GPU_BATCH / 1e3 / (dt / args.steps), 1)
@@ -515,7 +526,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

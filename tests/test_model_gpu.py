@@ -532,3 +532,26 @@ def test_inference_on_dataset_end_to_end(U, tmp_path):
         again = model([mapper(dicts[3])])[0]["sem_seg"]
     assert torch.equal(direct, again)
     record_parity("pipeline/inference_on_dataset", mIoU_random_weights=res["sem_seg"]["mIoU"], compute_s_per_iter=stats["compute_s_per_iter"])
+
+
+def test_rccl_call_path_on_one_gpu(U):
+    """The data-parallel exchange on REAL RCCL (no multi-GPU node is available to the tests): bench.py with UENC_DP_FORCE_COLLECTIVE=1
+    initialises the "nccl" (= RCCL) process group in a world of one rank and sends every gradient bucket through
+    dist.all_reduce(op=AVG, async_op=True) on views of the flat buffer, then waits -- exactly the calls the N > 1 path makes.  The mean
+    over one rank is the identity, so the loss and step time must match a run without the collectives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    torch.cuda.empty_cache()
+    plain = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    forced = subprocess.run(args, env={**env, "UENC_DP_FORCE_COLLECTIVE": "1"}, capture_output=True, text=True, timeout=600)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    a = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in forced.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "rccl_rehearsal" in b["config"] and "rccl_rehearsal" not in a["config"]
+    assert abs(a["loss"] - b["loss"]) <= 1e-4 * abs(a["loss"]), (a["loss"], b["loss"])
+    record_parity("dp/rccl_one_rank_rehearsal", loss_plain=a["loss"], loss_with_collectives=b["loss"], ms_plain=a["ms_per_step"], ms_with_collectives=b["ms_per_step"])

@@ -23,6 +23,7 @@ Design for MI355X / xGMI:
     rank checks that its own observation agrees, so ranks can never reduce different parameters against each other.
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -56,7 +57,10 @@ class GradBuckets:
         self._works = []
         # the 1 / world of the gradient mean rides in the collective where the backend can do it (RCCL: ncclAvg), so no
         # separate pass over the flat buffer follows the last all-reduce; gloo (CPU tests, rehearsal) sums and scales
-        self._avg_in_collective = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self._avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        # UENC_DP_FORCE_COLLECTIVE=1: issue the bucket all-reduces even in a world of one rank (the mean over one rank is the identity).
+        # The only way to run the RCCL call path -- ncclAvg, async handles on views of the flat buffer, the wait -- on a one-GPU box.
+        self._collective = self.world > 1 or (dist.is_initialized() and os.environ.get("UENC_DP_FORCE_COLLECTIVE") == "1")
         self._hooks = [p.register_post_accumulate_grad_hook(self._autograd_hook) for p in self.params]
         if listen_ops:
             from . import ops
@@ -113,7 +117,7 @@ class GradBuckets:
 
     def _launch(self, b: int):
         self._launched[b] = True
-        if self.world > 1:
+        if self._collective:
             s, e = self.bucket_ranges[b]
             if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
                 # functional rehearsal of N ranks on fewer GPUs (bench.py, UENC_DIST_BACKEND=gloo): the bucket is staged through
@@ -122,8 +126,13 @@ class GradBuckets:
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 self.flat[s:e].copy_(host)
                 return
-            op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-            self._works.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
+            if self._avg_in_collective:
+                try:
+                    self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                    return
+                except (RuntimeError, ValueError, TypeError):       # a communicator library without ncclAvg: refused before anything is
+                    self._avg_in_collective = False                 # enqueued, on every rank alike -> sum here, scale in finish()
+            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ---- step protocol --------------------------------------------------------------------------
     def zero_grad(self):
