@@ -9,6 +9,8 @@ Stated tolerances (relative L2 error over a tensor, `rel`):
   intermediate predictions)                       rel <= 6e-2, attention-mask agreement >= 99 %
   parameter gradients of the full model           rel <= 8e-2 (cosine >= 0.995)
 """
+import os
+
 import numpy as np
 import pytest
 import torch

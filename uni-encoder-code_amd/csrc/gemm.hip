@@ -509,7 +509,11 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
             for (int pr = 0; pr < 2; ++pr) {
                 const u32x2 lo = __builtin_amdgcn_permlane16_swap(o2[2 * pr][0], o2[2 * pr + 1][0], false, false);
                 const u32x2 hi = __builtin_amdgcn_permlane16_swap(o2[2 * pr][1], o2[2 * pr + 1][1], false, false);
-                if (row_ok && n16[pr] < p.N) *(u32x4*)((bf16*)p.C + (long)m * p.ldc + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+                if (row_ok && n16[pr] < p.N) {
+                    const u32x4 o4 = {lo[0], hi[0], lo[1], hi[1]};
+                    if (p.variant & 524288) __builtin_nontemporal_store(o4, (u32x4*)((bf16*)p.C + (long)m * p.ldc + n16[pr]));      // A/B: streaming stores
+                    else *(u32x4*)((bf16*)p.C + (long)m * p.ldc + n16[pr]) = o4;
+                }
             }
         }
         if (EPI == EPI_GELU && p.aux_out != nullptr) {
@@ -517,7 +521,11 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
             for (int pr = 0; pr < 2; ++pr) {
                 const u32x2 lo = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][0], pre2[2 * pr + 1][0], false, false);
                 const u32x2 hi = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][1], pre2[2 * pr + 1][1], false, false);
-                if (row_ok && n16[pr] < p.N) *(u32x4*)(p.aux_out + (long)m * p.ldaux_out + n16[pr]) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+                if (row_ok && n16[pr] < p.N) {
+                    const u32x4 o4 = {lo[0], hi[0], lo[1], hi[1]};
+                    if (p.variant & 524288) __builtin_nontemporal_store(o4, (u32x4*)(p.aux_out + (long)m * p.ldaux_out + n16[pr]));
+                    else *(u32x4*)(p.aux_out + (long)m * p.ldaux_out + n16[pr]) = o4;
+                }
             }
         }
     }
