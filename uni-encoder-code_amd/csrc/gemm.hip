@@ -445,10 +445,39 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
     // column at which this lane's 16-byte bf16 store of pair pr (column groups 2 pr, 2 pr + 1) starts
     const int odd = fg & 1;
     const int n16[2] = {nbase + (0 + odd) * 16 + 4 * (fg - odd), nbase + (2 + odd) * 16 + 4 * (fg - odd)};
+    // The saved activation / residual of ALL the wave's rows is requested before the first result store.  A wave's vector-memory
+    // operations retire in order, and the compiler may not move these loads above the stores (C and aux may alias as far as it knows):
+    // inside the row loop every row's load waited behind the previous row's stores -- eight load -> store round trips per tile,
+    // 64 us of a 124 us N = 3072 dGELU launch against 32 us for the same bytes streamed.  Four rows per batch = two round trips;
+    // all eight at once spilled (bit 1048576 of UENC_GEMM_VARIANT restores the per-row loads, A/B).
+    constexpr bool AUX16 = (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU);
+    const bool hoist = !(p.variant & 1048576);
+    u32x4 xa[AUX16 ? 4 : 1][2];                         // saved bf16 activation: four rows at a time (32 registers)
+    float4 ra[EPI == EPI_RESIDUAL ? 2 : 1][4];          // fp32 residual: two rows at a time (32 registers)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int m = mrow + j * 16;
         const bool row_ok = m < p.M;
+        if (AUX16 && hoist && (j & 3) == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int mm = mrow + (j + jj) * 16;
+                    xa[jj][pr] = (u32x4){0u, 0u, 0u, 0u};
+                    if (mm < p.M && n16[pr] < p.N) xa[jj][pr] = *(const u32x4*)((const bf16*)p.aux + (long)mm * p.ldaux + n16[pr]);
+                }
+        }
+        if (EPI == EPI_RESIDUAL && hoist && (j & 1) == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mm = mrow + (j + jj) * 16, n = ncol + i * 16;
+                    ra[jj][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (mm < p.M && n < p.N) ra[jj][i] = *(const float4*)((const float*)p.aux + (long)mm * p.ldaux + n);
+                }
+        }
         float v[4][4];
         const float al = nt_alpha(p, min(m, p.M - 1));
 #pragma unroll
@@ -473,7 +502,10 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = ncol + i * 16;
-                if (row_ok && n < p.N) {
+                if (hoist) {
+                    const float4 r0 = ra[j & 1][i];
+                    v[i][0] += r0.x; v[i][1] += r0.y; v[i][2] += r0.z; v[i][3] += r0.w;
+                } else if (row_ok && n < p.N) {
                     const float4 r0 = *(const float4*)((const float*)p.aux + (long)m * p.ldaux + n);
                     v[i][0] += r0.x; v[i][1] += r0.y; v[i][2] += r0.z; v[i][3] += r0.w;
                 }
@@ -484,7 +516,8 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 u32x4 x = {0u, 0u, 0u, 0u};
-                if (row_ok && n16[pr] < p.N) x = *(const u32x4*)((const bf16*)p.aux + (long)m * p.ldaux + n16[pr]);
+                if (hoist) x = xa[AUX16 ? (j & 3) : 0][pr];
+                else if (row_ok && n16[pr] < p.N) x = *(const u32x4*)((const bf16*)p.aux + (long)m * p.ldaux + n16[pr]);
                 const u32x2 lo = __builtin_amdgcn_permlane16_swap(x[0], x[2], false, false);
                 const u32x2 hi = __builtin_amdgcn_permlane16_swap(x[1], x[3], false, false);
                 const u32x2 sa = {lo[0], hi[0]}, sb = {lo[1], hi[1]};
@@ -540,6 +573,8 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
     constexpr int LDT = 260;
     const int erow = t >> 5, ecol = (t & 31) * 8;
     constexpr int RPI = NTHREADS / 32;            // rows one iteration of the workgroup covers
+    constexpr int NIT = 64 / RPI;
+    const bool hoist = !(p.variant & 1048576);
     const int n = n0 + ecol;
     const bool ncol_ok = n < p.N;
     const bool full8 = (n + 8 <= p.N);
@@ -552,6 +587,24 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
 #pragma unroll
     for (int ps = 0; ps < 2 * NWM; ++ps) {      // unrolled: acc[][] must keep compile-time indices (else it lives in scratch)
         __syncthreads();
+        // the pass's fp32 residual rows are requested here, ahead of the LDS transpose and of the previous pass's result stores in this
+        // wave's in-order memory queue (each (row, 8 columns) piece belongs to exactly one thread and iteration, so the order of
+        // these loads against other rows' stores does not matter even when aux aliases C); inside the row loop each load waited
+        // for the stores before it
+        float4 rres[EPI == EPI_RESIDUAL ? 4 : 1][2];              // four rows per batch (a 256-thread workgroup has eight per pass: two batches)
+        auto fetch_res = [&](int it0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + ps * 64 + (it0 + k) * RPI + erow;
+                rres[EPI == EPI_RESIDUAL ? k : 0][0] = rres[EPI == EPI_RESIDUAL ? k : 0][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.M) {
+                    const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                    rres[EPI == EPI_RESIDUAL ? k : 0][0] = *(const float4*)rp;
+                    if (full8) rres[EPI == EPI_RESIDUAL ? k : 0][1] = *(const float4*)(rp + 4);
+                }
+            }
+        };
+        if (EPI == EPI_RESIDUAL && hoist && ncol_ok) fetch_res(0);
         if (wm == (ps >> 1)) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -563,9 +616,10 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
         __syncthreads();
         if (!ncol_ok) continue;
 #pragma unroll
-        for (int it = 0; it < 64 / RPI; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int rl = it * RPI + erow;
             const int m = m0 + ps * 64 + rl;
+            if (EPI == EPI_RESIDUAL && hoist && it == 4) fetch_res(4);
             if (m >= p.M) continue;
             const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
             float v[8];
@@ -596,10 +650,16 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
             } else if (EPI == EPI_RESIDUAL) {
-                const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
-                const float4 r0 = *(const float4*)rp;
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
+                if (hoist) {
+                    const float4 r0 = rres[EPI == EPI_RESIDUAL ? (it & 3) : 0][0], r1 = rres[EPI == EPI_RESIDUAL ? (it & 3) : 0][1];
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                } else {
+                    const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                    const float4 r0 = *(const float4*)rp;
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                    if (full8) { const float4 r1 = *(const float4*)(rp + 4); v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w; }
+                }
             } else if (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU) {
                 const bf16* ap = (const bf16*)p.aux + (long)m * p.ldaux + n;
                 bf16x8 sv;
@@ -1021,7 +1081,8 @@ static bool nt128_wins(int M, int N, int K, int epilogue, int c_dtype, int varia
     // 1024 -> 256 FFN GEMM with the fp32 residual epilogue, the decoder's key / value projections over the 1/4-resolution map): every
     // A row is read once and the launch is store-bound.  Everywhere else its 1.5 x L2 -> LDS traffic and 1.5 x DMA instructions per
     // MFMA cost 4-30 %.
-    (void)M; (void)epilogue; (void)c_dtype;
+    (void)epilogue;
+    if (c_dtype == UENC_BF16 && M > 200000) return false;          // (262144, 256, 256) -> bf16: 6 % slower
     return N > 192 && N <= 288 && K <= 1024;
 }
 
