@@ -413,7 +413,7 @@ def main():
     dt = float(tmax)
 
     fams, alg_bytes = {}, {}
-    for kind, name in ((4, "gemm_nt256_kernel"), (0, "gemm_nt_kernel"), (1, "gemm_tn*_kernel")):
+    for kind, name in ((4, "gemm_nt256_kernel"), (5, "gemm_nt128_kernel"), (0, "gemm_nt_kernel"), (1, "gemm_tn*_kernel")):
         ms, fl, n, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
         capi.lib.uenc_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         capi.lib.uenc_prof_collect_bytes(kind, ctypes.byref(by))

@@ -317,7 +317,7 @@ int uenc_mha_f32_bwd(const float* q, long qs0, long qs1, const float* k, long ks
 
 /* ---- launch timers (opt-in, process-global): per-launch HIP events on the launch stream ---------------- */
 int uenc_prof_enable(int on); /* also resets */
-int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile), 1 gemm_tn*, 4 gemm_nt256 */, double* ms_total, double* flops_total, long* launches);
+int uenc_prof_collect(int kind /* 0 gemm_nt (128-tile, skinny), 1 gemm_tn*, 4 gemm_nt256, 5 gemm_nt128 */, double* ms_total, double* flops_total, long* launches);
 /* algorithmic bytes (operands read once + results written once) of the recorded launches of `kind` (gemm_nt kinds). */
 int uenc_prof_collect_bytes(int kind, double* bytes_total);
 /* algorithmic bytes of the NEXT recorded launch whose entry point cannot derive them (the grouped wgrad launches read their

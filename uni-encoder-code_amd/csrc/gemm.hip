@@ -1135,6 +1135,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
                      ((p.atomic || partials) ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
+    const bool half_tile = big && !p.atomic && !partials && (K % BK3 == 0) && nt128_wins(M, N, K, epilogue, c_dtype, p.variant);
     if (prof) {
         // algorithmic HBM bytes: A, W and the output once, plus what the epilogue reads (residual / saved activation) or writes besides
         const double mn = (double)M * N;
@@ -1142,7 +1143,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         if (epilogue == EPI_RESIDUAL) bytes += mn * 4;
         if (epilogue == EPI_MUL_DGELU || epilogue == EPI_MUL_DRELU) bytes += mn * 2;
         if (aux_out != nullptr) bytes += mn * 2;
-        uenc_prof_begin(big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream, batch * bytes);
+        uenc_prof_begin(half_tile ? UENC_PROF_GEMM_NT128 : big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream, batch * bytes);
     }
     // few output tiles (the decoder's M = 300-row GEMMs): the K-split 64 x 64 kernel
     const long tiles128 = (long)p.tiles_m * p.tiles_n;
@@ -1176,7 +1177,6 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         if (prof) uenc_prof_end(stream);
         UENC_LAUNCH_RET();
     }
-    const bool half_tile = big && !p.atomic && !partials && (K % BK3 == 0) && nt128_wins(M, N, K, epilogue, c_dtype, p.variant);
     if (big) {
         int rc = UENC_EINVAL;
 #define LAUNCH2(E, F) rc = half_tile ? launch_nt128<E, F>(p, stream) : (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */

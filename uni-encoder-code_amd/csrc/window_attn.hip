@@ -28,6 +28,7 @@
 // Algorithmic HBM bytes per token per head: fwd read 3*64 + write 64; bwd read 5*64 + write 3*64.
 #include "common.h"
 #include "lds_frag.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #define LOG2E 1.4426950408889634f
@@ -47,6 +48,7 @@ struct WAttn {
     float* dpad;            // (3C) q|k|v bias gradient that reaches the heads through padding slots: ADDED (atomics) to the caller's buffer
     int B, H, W, C, nH, ws, shift, Hp, Wp, nWw, nWin, nWinTotal, N;
     float scale;
+    int variant;            // UENC_WATTN_VARIANT (A/B switches, 0 in production)
 };
 
 template <int NTILES>
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         const int qtok = ((const int*)(smem + OFF_TOK))[wave * 16 + fr];
         if (qtok >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
     }
+    const bool wait_at_top = (p.variant & 1) != 0;          // bit 0: the round-2 placement of the stage wait (A/B)
     for (int it = 0; win < p.nWinTotal; ++it, win += G) {
         const int st = it & 1;
         const unsigned char* Qs = smem + st * STAGE;
@@ -322,7 +325,10 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
         const bf16x8 ov = o_next;
         if (more) slots(win + G, st ^ 1);
-        __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): this wave's share of the current stage has landed (and bq)
+        // This wave's share of the current stage has landed: for the first window by the wait here; for the others by the wait in
+        // front of the previous window's dK / dV stores (below).  A wave's vector-memory operations retire in order, so a vmcnt(0)
+        // HERE would also wait for those stores to be acknowledged -- with one workgroup per CU nothing else runs meanwhile.
+        if (it == 0 || wait_at_top) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();                               // ... everyone's; next window's slots are visible
         if (more) {
             issue(st ^ 1);
@@ -475,6 +481,10 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                     dk[dt] = mfma16(frag_tr(Qs, 32 * qb, 32 * qb + 16, dt * 16, lane), db, dk[dt]);    // dK^T += Q^T dS
                 }
             }
+            // the next window's q / k / v / dO rows (LDS-DMA issued at the top of this iteration) have had both phases to land: waiting for
+            // them here, BEFORE this window's last stores enter the queue, costs nothing and leaves the stores to drain under the next
+            // window's phase A
+            if (!wait_at_top) __builtin_amdgcn_s_waitcnt(0x0f70);
             if (ktok != -2) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -580,6 +590,7 @@ static int fill_params(WAttn& p, const void* qkv, const void* qkv_bias, const fl
     p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
     p.nWw = p.Wp / ws; p.nWin = (p.Hp / ws) * p.nWw; p.nWinTotal = B * p.nWin; p.N = ws * ws;
     p.scale = scale;
+    { const char* e = getenv("UENC_WATTN_VARIANT"); p.variant = e ? atoi(e) : 0; }
     p.out = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab_ws = nullptr; p.dpad = nullptr;
     return UENC_OK;
 }
