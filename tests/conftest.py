@@ -18,6 +18,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# oracle/ref_loader.py seeds sys.modules with name holders (`model`, `detectron2`, `timm`, `fvcore`, `cv2`, ...) so that the reference's
+# files import in the build container.  They must not outlive the test that needed them: the product's own `model` facade and its
+# "is detectron2 installed?" probe would otherwise see them, depending on the order the test files run in.
+_STUB_ROOTS = ("model", "detectron2", "timm", "fvcore", "cv2", "skimage", "matplotlib", "natten")
+
+
+@pytest.fixture(autouse=True)
+def _isolate_reference_stubs():
+    before = {k: v for k, v in sys.modules.items() if k.split(".")[0] in _STUB_ROOTS}
+    yield
+    rl = sys.modules.get("oracle.ref_loader")
+    if rl is None or not getattr(rl, "_installed", False):
+        return
+    for k in [k for k in sys.modules if k.split(".")[0] in _STUB_ROOTS and k not in before]:
+        del sys.modules[k]
+    sys.modules.update(before)
+    rl._installed = False
+
+
 def load_golden(name):
     """npz fixture -> dict of torch tensors (strings/ints stay numpy)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

@@ -122,3 +122,24 @@ def test_yaml_eval_tag_is_checked_before_evaluation(tmp_path):
         bad.write_text(f'A: !!python/object/apply:eval ["{expr}"]\n')
         with pytest.raises(ValueError):
             CfgNode.load_yaml_with_base(str(bad))
+
+
+def test_mask_bounding_boxes_match_the_per_mask_loop():
+    """MODEL.TEST.DETECTION_ON (reference oneformer_model.py:478-480): boxes from the binary masks, as detectron2's
+    BitMasks.get_bounding_boxes computes them mask by mask."""
+    import torch
+    from uenc.oneformer_model import mask_bounding_boxes
+    g = torch.Generator().manual_seed(0)
+    m = torch.rand(7, 13, 17, generator=g) > 0.93
+    m[2] = False                                     # an empty mask -> zeros
+    m[3] = False; m[3, 5, 9] = True                  # a single pixel
+    m[4] = True                                      # everything
+    want = torch.zeros(7, 4)
+    for i in range(7):
+        x = torch.where(m[i].any(0))[0]; y = torch.where(m[i].any(1))[0]
+        if len(x) and len(y):
+            want[i] = torch.tensor([x[0], y[0], x[-1] + 1, y[-1] + 1], dtype=torch.float32)
+    got = mask_bounding_boxes(m)
+    assert torch.equal(got, want) and got.dtype == torch.float32
+    assert tuple(got[3].tolist()) == (9.0, 5.0, 10.0, 6.0) and tuple(got[4].tolist()) == (0.0, 0.0, 17.0, 13.0)
+    assert mask_bounding_boxes(torch.zeros(0, 4, 4, dtype=torch.bool)).shape == (0, 4)

@@ -47,3 +47,4 @@ def test_oracle_matches_reference_live():
         seg, info = P.panoptic_inference(cls, mp, 7, 0.4, 0.7, [5, 6])
         seg2, info2 = O.panoptic_inference(fake, cls, mp)
         assert torch.equal(seg, seg2) and info == info2
+

@@ -146,3 +146,19 @@ def test_oneformer_forward_inference_paths_agree():
     assert len(fi) == len(si) and torch.equal(fi.pred_classes[of], si.pred_classes[os_])
     torch.testing.assert_close(fi.scores[of], si.scores[os_].detach(), atol=1e-5, rtol=1e-4)
     assert fi.image_size == (90, 120) and tuple(fi.pred_masks.shape[-2:]) == (90, 120)
+    assert "box_instances" not in fused                                   # MODEL.TEST.DETECTION_ON is off by default
+    # reference :301-304, :478-480: with DETECTION_ON a second instance pass whose boxes are the tight boxes of the binary masks
+    m.detection_on = True
+    with torch.no_grad():
+        det = m(batch)[0]["box_instances"]
+    m.detection_on = False
+    assert len(det) == len(fi) and tuple(det.pred_boxes.tensor.shape) == (len(det), 4)
+    for k in range(len(det)):
+        mk = det.pred_masks[k] > 0
+        x1, y1, x2, y2 = [float(v) for v in det.pred_boxes.tensor[k]]
+        if bool(mk.any()):
+            ys, xs = torch.where(mk)
+            assert (x1, y1, x2, y2) == (float(xs.min()), float(ys.min()), float(xs.max()) + 1, float(ys.max()) + 1)
+        else:
+            assert (x1, y1, x2, y2) == (0.0, 0.0, 0.0, 0.0)
+    assert float(fi.pred_boxes.tensor.abs().sum()) == 0.0                   # detection off: zeros, as the reference

@@ -22,11 +22,15 @@ import torch.utils.data as torchdata
 logger = logging.getLogger(__name__)
 
 try:  # pragma: no cover - not installable in the build image
+    import detectron2
+    if not (hasattr(detectron2, "__version__") and getattr(detectron2, "__file__", None) is not None):      # a test's name holder
+        raise ImportError("detectron2 is not installed")
     from detectron2.data import DatasetCatalog, MetadataCatalog
     HAVE_D2 = True
 except Exception:
     HAVE_D2 = False
 
+if not HAVE_D2:
     class _Metadata:
         def __init__(self, name):
             object.__setattr__(self, "name", name)

@@ -26,6 +26,22 @@ from .modeling.transformer_decoder.oneformer_transformer_decoder import MLP
 from .tokenizer import Tokenize
 
 
+def mask_bounding_boxes(masks: torch.Tensor) -> torch.Tensor:
+    """detectron2.structures.BitMasks.get_bounding_boxes [not in reference] for (N, H, W) boolean masks: (x1, y1, x2 + 1, y2 + 1) of the
+    pixels that are set, zeros for an empty mask; float32 on the masks' device.  All masks at once (Detectron2 loops over them with
+    a torch.where per mask and axis)."""
+    n, h, w = masks.shape
+    out = torch.zeros((n, 4), dtype=torch.float32, device=masks.device)
+    if n == 0:
+        return out
+    xs, ys = masks.any(dim=1), masks.any(dim=2)                       # (N, W), (N, H)
+    has = xs.any(dim=1)
+    first = lambda a: a.to(torch.uint8).argmax(dim=1)                 # index of the first True (0 for an all-False row)
+    last = lambda a: a.shape[1] - 1 - a.flip(1).to(torch.uint8).argmax(dim=1)
+    box = torch.stack([first(xs), first(ys), last(xs) + 1, last(ys) + 1], dim=1).to(torch.float32)
+    return torch.where(has[:, None], box, out)
+
+
 @META_ARCH_REGISTRY.register()
 class OneFormer(nn.Module):
     @configurable
@@ -33,7 +49,7 @@ class OneFormer(nn.Module):
                  num_queries: int, object_mask_threshold: float,
                  overlap_threshold: float, size_divisibility: int, sem_seg_postprocess_before_inference: bool,
                  pixel_mean: Tuple[float], pixel_std: Tuple[float], semantic_on: bool, panoptic_on: bool, instance_on: bool,
-                 test_topk_per_image: int, task_seq_len: int, max_seq_len: int, is_demo: bool, **unused):
+                 test_topk_per_image: int, task_seq_len: int, max_seq_len: int, is_demo: bool, detection_on: bool = False, **unused):
         super().__init__()
         self.backbone, self.sem_seg_head, self.task_mlp = backbone, sem_seg_head, task_mlp
         # the sequence branch's decoders (reference :66-68, built unconditionally at :143-145: they are part of the state dict)
@@ -48,6 +64,7 @@ class OneFormer(nn.Module):
         self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
         self.semantic_on, self.instance_on, self.panoptic_on = semantic_on, instance_on, panoptic_on
+        self.detection_on = detection_on        # reference :121, :301-304, :478-480: "box_instances" with boxes taken from the binary masks
         self.test_topk_per_image = test_topk_per_image
         self.task_tokenizer = Tokenize(max_seq_len=task_seq_len)
         self.is_demo = is_demo
@@ -71,7 +88,7 @@ class OneFormer(nn.Module):
             "size_divisibility": cfg.MODEL.ONE_FORMER.SIZE_DIVISIBILITY,
             "sem_seg_postprocess_before_inference": (t.SEM_SEG_POSTPROCESSING_BEFORE_INFERENCE or t.PANOPTIC_ON or t.INSTANCE_ON),
             "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
-            "semantic_on": t.SEMANTIC_ON, "instance_on": t.INSTANCE_ON, "panoptic_on": t.PANOPTIC_ON,
+            "semantic_on": t.SEMANTIC_ON, "instance_on": t.INSTANCE_ON, "panoptic_on": t.PANOPTIC_ON, "detection_on": t.DETECTION_ON,
             "test_topk_per_image": cfg.TEST.DETECTIONS_PER_IMAGE,
             "task_seq_len": cfg.INPUT.TASK_SEQ_LEN, "max_seq_len": cfg.INPUT.MAX_SEQ_LEN, "is_demo": cfg.MODEL.IS_DEMO,
         }
@@ -170,6 +187,8 @@ class OneFormer(nn.Module):
                     r["panoptic_seg"] = self.panoptic_inference_fused(mask_cls.detach().float(), ml, padded, tuple(image_size))
                 if self.instance_on:
                     r["instances"] = self.instance_inference(mask_cls.detach().float(), ml, inp["task"], padded, tuple(image_size))
+                if self.detection_on:
+                    r["box_instances"] = self.instance_inference(mask_cls.detach().float(), ml, inp["task"], padded, tuple(image_size))
             else:
                 if mask_pred_results is None:
                     mask_pred_results = self.upsample_masks(outputs["pred_masks"], padded)
@@ -189,6 +208,8 @@ class OneFormer(nn.Module):
                     r["panoptic_seg"] = self.panoptic_inference(mask_cls, mp)
                 if self.instance_on:
                     r["instances"] = self.instance_inference(mask_cls, mp, inp["task"])
+                if self.detection_on:
+                    r["box_instances"] = self.instance_inference(mask_cls, mp, inp["task"])
             results.append(r)
         return results
 
@@ -262,7 +283,8 @@ class OneFormer(nn.Module):
             mask_pred = mask_pred[qidx]
         result = Instances(tuple(mask_pred.shape[-2:]))
         result.pred_masks = (mask_pred > 0).float()
-        result.pred_boxes = Boxes(torch.zeros(mask_pred.size(0), 4))
+        # reference :478-482: with MODEL.TEST.DETECTION_ON the boxes are the tight boxes of the binary masks, else zeros
+        result.pred_boxes = Boxes(mask_bounding_boxes(mask_pred > 0) if self.detection_on else torch.zeros(mask_pred.size(0), 4))
         flat = result.pred_masks.flatten(1)
         mask_scores_per_image = (mask_pred.sigmoid().flatten(1) * flat).sum(1) / (flat.sum(1) + 1e-6)
         result.scores = scores_per_image * mask_scores_per_image
