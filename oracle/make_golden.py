@@ -18,6 +18,7 @@ Fixture list:
   F9 task_tokens       tokenizer ids of the three task prompts + task_mlp output
   F10 model_fwd_bwd    small full model: loss and selected parameter gradients
   F11 decoder_contrastive  F7's inputs through the decoder built with is_train=True: `contrastive_logits` and gradients of a loss on it
+  F12 swin_ape         SwinTransformer with APE = True and non-zero drop rates (eval mode): features and the embedding's gradient
 
 `python -m oracle.make_golden NAME [NAME ...]` regenerates only the named fixtures (F11: decoder_contrastive).
 """
@@ -99,6 +100,22 @@ def decoder_contrastive(ref):
           grad_ct_l1_linear2_bias=named["class_transformer.decoder.layers.1.linear2.bias"].grad)
 
 
+def swin_ape(ref):
+    """F12: the reference SwinTransformer built with ape=True (absolute position embedding at pretrain_img_size 64, resized bicubically
+    to the token grid of a 64 x 96 input, swin.py:566-578, 656-661) and drop_rate = attn_drop_rate = 0.1 (identity in eval mode),
+    C 64, depths 1-1-1-1, ws 7; forward and the embedding's gradient under a fixed linear loss."""
+    m = ref.swin.SwinTransformer(pretrain_img_size=64, embed_dim=64, depths=[1, 1, 1, 1], num_heads=[2, 4, 8, 16], window_size=7,
+                                 drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.0, ape=True)
+    m.eval()
+    fill.fill_module(m, "backbone.")
+    img = _randn(12, 1, 3, 64, 96)
+    o = m(img)
+    wts = {k: _randn(40 + i, *o[k].shape) for i, k in enumerate(sorted(o))}
+    sum((o[k] * wts[k]).sum() for k in o).backward()
+    _save("swin_ape", img=img, grad_ape=m.absolute_pos_embed.grad, ape_shape=np.array(m.absolute_pos_embed.shape),
+          **{k: v for k, v in o.items()}, **{"w_" + k: v for k, v in wts.items()})
+
+
 def main():
     warnings.filterwarnings("ignore")
     assert ref_loader.available(), "needs /root/reference"
@@ -109,7 +126,7 @@ def main():
     only = set(sys.argv[1:])
     if only:
         for name in only:
-            {"decoder_contrastive": decoder_contrastive}[name](ref)
+            {"decoder_contrastive": decoder_contrastive, "swin_ape": swin_ape}[name](ref)
         return
 
     # F1 / F2: block pairs through the reference BasicLayer (builds the shift mask itself)
@@ -245,6 +262,7 @@ def main():
     _save("model_fwd_bwd", img0=imgs[0].byte(), img1=imgs[1].byte(), loss=loss.detach(), pred_logits=o["pred_logits"],
           pred_masks=o["pred_masks"], grad_names=np.array(pick), grad_norm=np.array(sq ** 0.5), **grads)
     decoder_contrastive(ref)
+    swin_ape(ref)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "python -m oracle.make_golden", "torch": torch.__version__,
                    "note": "inputs + outputs of the reference's modules with name-hashed weights (oracle/fill.py)"}, f, indent=1)

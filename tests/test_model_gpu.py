@@ -557,3 +557,28 @@ def test_rccl_call_path_on_one_gpu(U):
     assert "rccl_rehearsal" in b["config"] and "rccl_rehearsal" not in a["config"]
     assert abs(a["loss"] - b["loss"]) <= 1e-4 * abs(a["loss"]), (a["loss"], b["loss"])
     record_parity("dp/rccl_one_rank_rehearsal", loss_plain=a["loss"], loss_with_collectives=b["loss"], ms_plain=a["ms_per_step"], ms_with_collectives=b["ms_per_step"])
+
+
+def test_swin_absolute_position_embedding_vs_reference_fixture(U):
+    """MODEL.SWIN.APE = True (reference swin.py:566-578, 656-661) against a fixture from the reference module (oracle/make_golden.py F12):
+    the embedding, defined at the pre-training resolution, is resized bicubically to the token grid and added before stage 1.  The model
+    also carries DROP_RATE = ATTN_DROP_RATE = 0.1: identity in eval mode (it builds and infers), refused in a training forward."""
+    from uenc import ops
+    from uenc.modeling.backbone.swin import SwinTransformer
+    g = load_golden("swin_ape")
+    m = SwinTransformer(pretrain_img_size=64, embed_dim=64, depths=[1, 1, 1, 1], num_heads=[2, 4, 8, 16], window_size=7,
+                        drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.0, ape=True)
+    assert tuple(m.absolute_pos_embed.shape) == tuple(int(v) for v in g["ape_shape"])
+    _fill(m, "backbone.")
+    m = m.cuda()
+    m.eval()
+    o = m(g["img"].cuda())
+    figs = {k: rel(o[k], g[k]) for k in ("res2", "res3", "res4", "res5")}
+    sum((o[k] * g["w_" + k].cuda()).sum() for k in figs).backward()
+    ops.flush_wgrads()
+    figs["grad_ape"] = rel(m.absolute_pos_embed.grad, g["grad_ape"])
+    record_parity("bf16/swin_ape_64x96", **figs)
+    assert max(figs[k] for k in ("res2", "res3", "res4", "res5")) < 1.5e-2 and figs["grad_ape"] < 3e-2, figs
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(g["img"].cuda())

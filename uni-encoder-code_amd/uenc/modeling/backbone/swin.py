@@ -184,15 +184,17 @@ class SwinTransformer(nn.Module):
                  attn_drop_rate=0.0, drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
                  out_indices=(0, 1, 2, 3), frozen_stages=-1, use_checkpoint=False):
         super().__init__()
-        if ape:
-            raise NotImplementedError("absolute position embedding is not on the shipped config's path (APE: False)")
-        if drop_rate != 0.0 or attn_drop_rate != 0.0:
-            # refused rather than silently ignored: a model built with these would train differently from the reference's
-            raise NotImplementedError("MODEL.SWIN.DROP_RATE / ATTN_DROP_RATE > 0 are not implemented in the fused Swin block "
-                                      "(0.0 in every shipped config, config.py:192-214); stochastic depth (DROP_PATH_RATE) is")
+        # MODEL.SWIN.DROP_RATE / ATTN_DROP_RATE (pos_drop, Mlp.drop, proj_drop, attn_drop of reference swin.py:33-40, 124-126, 580): 0.0 in
+        # every shipped config.  Identity in eval mode, so such a model builds and infers; a TRAINING forward with them refuses
+        # (forward below) rather than silently train differently from the reference.  Stochastic depth (DROP_PATH_RATE) is implemented.
+        self.drop_rate, self.attn_drop_rate = float(drop_rate), float(attn_drop_rate)
         self.pretrain_img_size, self.num_layers, self.embed_dim = pretrain_img_size, len(depths), embed_dim
         self.ape, self.patch_norm, self.out_indices, self.frozen_stages = ape, patch_norm, out_indices, frozen_stages
         self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, norm_layer if patch_norm else None)
+        if ape:          # absolute position embedding at the pre-training resolution (reference swin.py:566-578), resized per input below
+            pi, ps = to_2tuple(pretrain_img_size), to_2tuple(patch_size)
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, pi[0] // ps[0], pi[1] // ps[1]))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=0.02)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
@@ -222,7 +224,13 @@ class SwinTransformer(nn.Module):
         """No-op, as in the reference (swin.py:635-649 defines but never applies its initialiser)."""
 
     def forward(self, x):
+        if self.training and (self.drop_rate != 0.0 or self.attn_drop_rate != 0.0):
+            raise NotImplementedError("training with MODEL.SWIN.DROP_RATE / ATTN_DROP_RATE > 0 is not implemented in the fused Swin block "
+                                      "(0.0 in every shipped config, config.py:192-214); inference with such a model is")
         x, Wh, Ww = self.patch_embed.forward_tokens(x)
+        if self.ape:     # reference swin.py:656-661: bicubic resize of the embedding to the token grid, added before the first stage
+            pe = F.interpolate(self.absolute_pos_embed, size=(Wh, Ww), mode="bicubic")
+            x = x + pe.flatten(2).transpose(1, 2)
         outs = {}
         for i in range(self.num_layers):
             x_out, H, W, x, Wh, Ww = self.layers[i](x, Wh, Ww)
