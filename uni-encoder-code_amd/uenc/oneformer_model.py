@@ -284,7 +284,7 @@ class OneFormer(nn.Module):
         result = Instances(tuple(mask_pred.shape[-2:]))
         result.pred_masks = (mask_pred > 0).float()
         # reference :478-482: with MODEL.TEST.DETECTION_ON the boxes are the tight boxes of the binary masks, else zeros
-        result.pred_boxes = Boxes(mask_bounding_boxes(mask_pred > 0) if self.detection_on else torch.zeros(mask_pred.size(0), 4))
+        result.pred_boxes = Boxes(mask_bounding_boxes(mask_pred > 0) if getattr(self, "detection_on", False) else torch.zeros(mask_pred.size(0), 4))
         flat = result.pred_masks.flatten(1)
         mask_scores_per_image = (mask_pred.sigmoid().flatten(1) * flat).sum(1) / (flat.sum(1) + 1e-6)
         result.scores = scores_per_image * mask_scores_per_image
