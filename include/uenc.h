@@ -231,6 +231,21 @@ int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int64_t* shapes
                            float* grad_loc, float* grad_attn, int B, int S, int M, int D, int L, int Lq, int P,
                            const int64_t* shapes_host, void* workspace, long workspace_bytes, uenc_stream_t stream);
 long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, int M, int D, int L, int Lq, int P);
+/* Fused form of the same op for callers that own the two projection Linears around it (ops/modules/ms_deform_attn.py:99-125): instead
+ * of sampling locations and attention weights the kernels take the projection row they are derived from,
+ *   offaw (B * Lq, ld) fp32 = [M][L][P][2] sampling offsets | [M][L * P] attention logits   (sampling_offsets | attention_weights Linear outputs),
+ * the reference points ref (B | 1, Lq, L, 2) fp32 (ref_per_image: 1 if ref has a batch dimension) and the level shapes:
+ * loc = ref + off / (W_l, H_l), attn = softmax over the L * P logits, both computed inside the kernels.  The backward writes
+ * d(offaw) (B * Lq, ld_doffaw) bf16 (all 3 M L P columns) and accumulates grad_value (caller zeroes) -- grad_loc / grad_attn never exist.
+ * L * P <= 16, D == 32, ld even; the backward needs shapes_host + workspace (uenc_msdeform_attn_bwd_workspace_bytes() > 0) and
+ * returns -1 otherwise.  Same sums as uenc_msda_prep_fwd + uenc_msdeform_attn_fwd (and the backward pair). */
+int uenc_msdeform_attn_fused_fwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
+                                 long ld, const float* ref, int ref_per_image, void* out, int out_dtype, int B, int S, int M, int D,
+                                 int L, int Lq, int P, uenc_stream_t stream);
+int uenc_msdeform_attn_fused_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
+                                 long ld, const float* ref, int ref_per_image, const void* grad_out, int go_dtype, float* grad_value,
+                                 void* doffaw, long ld_doffaw, int B, int S, int M, int D, int L, int Lq, int P, const int64_t* shapes_host,
+                                 void* workspace, long workspace_bytes, uenc_stream_t stream);
 
 /* ---- decoder multi-head attention core (head_dim 32) --------------------------------------------------------
  * softmax(scale * q k^T [blocked where mask != 0]) v for every nn.MultiheadAttention of the transformer decoder

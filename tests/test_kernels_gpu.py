@@ -456,3 +456,46 @@ def test_weight_gradient_alpha(K, M, N, K_):
     want2 = 1.5 * (dy[M // 2:].float().t() @ x[M // 2:].float())
     _close(gw2, want2, 3e-3 * float(want2.abs().max()), 3e-3)
     _close(gb2, 1.5 * dy[M // 2:].float().sum(0), 3e-3 * float(want_b.abs().max()), 3e-3)
+
+
+@pytest.mark.parametrize("shapes_l,spread,ref_batch", [([(8, 16), (16, 32), (32, 64)], 4.0, False), ([(7, 11), (13, 22), (27, 43)], 30.0, True)])
+def test_msdeform_fused_equals_prep_plus_core(K, shapes_l, spread, ref_batch):
+    """The fused entry points (sampling locations and softmaxed weights derived INSIDE the attention kernels from the projection row,
+    reference ops/modules/ms_deform_attn.py:99-125) against the pair they replace -- uenc_msda_prep_* + uenc_msdeform_attn_* -- on the
+    same inputs: identical forward output, grad_value within the float-atomics order, d(offaw) within bf16 rounding of the last step
+    (the fused backward skips the fp32 grad_loc / grad_attn round trip, nothing else); incl. borders, out-of-range samples, a ragged last
+    workgroup, reference points with and without a batch dimension, and a padded row stride."""
+    L, P, M, D, B = len(shapes_l), 4, 8, 32, 2
+    S = sum(h * w for h, w in shapes_l)
+    gen = torch.Generator().manual_seed(5)
+    ref1 = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1).reshape(-1, 2).flip(-1)
+                      for h, w in shapes_l])                                                    # (S, 2) as (x, y)
+    ref = ref1[None, :, None, :].expand(B if ref_batch else 1, S, L, 2).contiguous()
+    if ref_batch:
+        ref = ref + 0.01 * torch.randn(ref.shape, generator=gen)
+    ncol = 3 * M * L * P
+    ld = ncol + 8                                                                               # a padded projection row
+    offaw_full = torch.zeros(B * S, ld)
+    offaw_full[:, : 2 * M * L * P] = (torch.rand(B * S, 2 * M * L * P, generator=gen) * 2 - 1) * spread
+    offaw_full[:, 2 * M * L * P: ncol] = torch.randn(B * S, M * L * P, generator=gen) * 2
+    offaw = offaw_full.cuda()[:, :ncol]                                                         # (B * S, ncol) view with stride ld
+    value = torch.randn(B, S, M, D, generator=gen).to(torch.bfloat16).cuda()
+    go = torch.randn(B, S, M * D, generator=gen).to(torch.bfloat16).cuda()
+    shapes = torch.tensor(shapes_l, dtype=torch.int64).cuda()
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    refd = ref.cuda()
+    assert K.msdeform_fused_available(shapes_l, B, M, D, L, S, P)
+    # the pair
+    loc, aw = K.msda_prep_fwd(offaw, refd, shapes, B, S, M, L, P)
+    out0 = K.msdeform_attn_fwd(value, shapes, start, loc, aw, out_dtype=torch.bfloat16)
+    gv0, gl0, ga0 = K.msdeform_attn_bwd(value, shapes, start, loc, aw, go, shapes_host=shapes_l)
+    d0 = K.msda_prep_bwd(gl0, ga0, aw, shapes, ncol)
+    # fused
+    out1 = K.msdeform_attn_fused_fwd(value, shapes, start, offaw, refd, L, P, out_dtype=torch.bfloat16)
+    gv1, d1 = K.msdeform_attn_fused_bwd(value, shapes, start, offaw, refd, L, P, go, shapes_l)
+    assert torch.equal(out0, out1)                                                              # the same arithmetic, term for term
+    _close(gv1, gv0, 2e-5 * float(gv0.abs().max()) + 1e-6, 1e-4)
+    assert tuple(d1.shape) == (B * S, ncol) and d1.dtype == torch.bfloat16
+    den = float(d0.float().abs().max())
+    assert float((d1.float() - d0.float()).abs().max()) <= 2 ** -7 * den                       # one bf16 ulp of the largest entries
+    assert float((d1.float() - d0.float()).norm() / d0.float().norm()) < 2e-3

@@ -27,6 +27,12 @@ struct MsdaP {
     float* grad_loc;             // (B, Lq, M, L, P, 2)
     float* grad_attn;            // (B, Lq, M, L, P)
     int B, S, M, D, L, Lq, P;
+    // fused form (uenc_msdeform_attn_fused_*): locations and weights are derived in the kernel from the projection row
+    //   offaw (B * Lq, ld) fp32 = [M][L][P][2] sampling offsets | [M][L * P] attention logits,  ref (B|1, Lq, L, 2):
+    //   loc = ref + off / (W_l, H_l), attn = softmax over the L * P logits (ops/modules/ms_deform_attn.py:101-113)
+    const float* offaw; long ld;
+    const float* ref; int ref_per_image;
+    bf16* doffaw; long ldd;      // backward: d(offaw) (B * Lq, ldd) bf16, every column of the 3 M L P written
 };
 
 __device__ __forceinline__ float4 ldv4(const void* base, int is_f32, long idx) {
@@ -35,7 +41,28 @@ __device__ __forceinline__ float4 ldv4(const void* base, int is_f32, long idx) {
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
-template <int LPG>
+// one bilinear sample (x, y in [0, 1], weight w) of level (Hl, Wl) added to acc: 4 channels of this lane
+__device__ __forceinline__ void msda_fwd_sample(const MsdaP& p, float x, float y, float w, int Hl, int Wl, long lbase, long vstride, float4& acc) {
+    const float him = y * Hl - 0.5f, wim = x * Wl - 0.5f;
+    if (him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl) {
+        const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+        const float lh = him - h0, lw = wim - w0, hh = 1.f - lh, hw = 1.f - lw;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v1 = z, v2 = z, v3 = z, v4 = z;
+        const long r0 = lbase + ((long)h0 * Wl + w0) * vstride;
+        if (h0 >= 0 && w0 >= 0) v1 = ldv4(p.value, p.v_f32, r0);
+        if (h0 >= 0 && w0 + 1 <= Wl - 1) v2 = ldv4(p.value, p.v_f32, r0 + vstride);
+        if (h0 + 1 <= Hl - 1 && w0 >= 0) v3 = ldv4(p.value, p.v_f32, r0 + (long)Wl * vstride);
+        if (h0 + 1 <= Hl - 1 && w0 + 1 <= Wl - 1) v4 = ldv4(p.value, p.v_f32, r0 + (long)Wl * vstride + vstride);
+        const float w1 = hh * hw * w, w2 = hh * lw * w, w3 = lh * hw * w, w4 = lh * lw * w;
+        acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+        acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+        acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+        acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    }
+}
+
+template <int LPG, bool FUSED>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaP p) {
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long grp = gtid / LPG;
@@ -46,34 +73,37 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaP p) {
     const long bq = grp / p.M;
     const int b = (int)(bq / p.Lq);
     const int LP = p.L * p.P;
-    const float* loc = p.loc + grp * LP * 2;
-    const float* aw = p.attn + grp * LP;
     const long vstride = (long)p.M * p.D;               // between spatial positions
     const long vbase = (long)b * p.S * vstride + (long)m * p.D + c4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = 0; l < p.L; ++l) {
-        const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
-        const long lbase = vbase + p.level_start[l] * vstride;
-        for (int k = 0; k < p.P; ++k) {
-            const float x = loc[(l * p.P + k) * 2], y = loc[(l * p.P + k) * 2 + 1];
-            const float w = aw[l * p.P + k];
-            const float him = y * Hl - 0.5f, wim = x * Wl - 0.5f;
-            if (him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl) {
-                const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
-                const float lh = him - h0, lw = wim - w0, hh = 1.f - lh, hw = 1.f - lw;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 v1 = z, v2 = z, v3 = z, v4 = z;
-                const long r0 = lbase + ((long)h0 * Wl + w0) * vstride;
-                if (h0 >= 0 && w0 >= 0) v1 = ldv4(p.value, p.v_f32, r0);
-                if (h0 >= 0 && w0 + 1 <= Wl - 1) v2 = ldv4(p.value, p.v_f32, r0 + vstride);
-                if (h0 + 1 <= Hl - 1 && w0 >= 0) v3 = ldv4(p.value, p.v_f32, r0 + (long)Wl * vstride);
-                if (h0 + 1 <= Hl - 1 && w0 + 1 <= Wl - 1) v4 = ldv4(p.value, p.v_f32, r0 + (long)Wl * vstride + vstride);
-                const float w1 = hh * hw * w, w2 = hh * lw * w, w3 = lh * hw * w, w4 = lh * lw * w;
-                acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-                acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-                acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-                acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    if (FUSED) {
+        // softmax statistics first, then every sample's weight and location from the projection row as it is needed (L1-resident:
+        // the group's 8 lanes read the same 144 bytes) -- nothing is held in register arrays, the kernel keeps its occupancy
+        const float* off = p.offaw + bq * p.ld + (long)m * LP * 2;
+        const float* lg = p.offaw + bq * p.ld + (long)p.M * LP * 2 + (long)m * LP;
+        const float* rf = p.ref + (p.ref_per_image ? bq : bq % p.Lq) * p.L * 2;
+        float mx = -3.0e38f, sum = 0.f;
+        for (int j = 0; j < LP; ++j) mx = fmaxf(mx, lg[j]);
+        for (int j = 0; j < LP; ++j) sum += __expf(lg[j] - mx);
+        const float inv = 1.0f / sum;
+        for (int l = 0; l < p.L; ++l) {
+            const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
+            const long lbase = vbase + p.level_start[l] * vstride;
+            const float rx = rf[2 * l], ry = rf[2 * l + 1];
+            for (int k = 0; k < p.P; ++k) {
+                const int j = l * p.P + k;
+                const float2 o = *(const float2*)(off + 2 * j);
+                msda_fwd_sample(p, rx + o.x / (float)Wl, ry + o.y / (float)Hl, __expf(lg[j] - mx) * inv, Hl, Wl, lbase, vstride, acc);
             }
+        }
+    } else {
+        const float* loc = p.loc + grp * LP * 2;
+        const float* aw = p.attn + grp * LP;
+        for (int l = 0; l < p.L; ++l) {
+            const int Hl = (int)p.shapes[2 * l], Wl = (int)p.shapes[2 * l + 1];
+            const long lbase = vbase + p.level_start[l] * vstride;
+            for (int k = 0; k < p.P; ++k)
+                msda_fwd_sample(p, loc[(l * p.P + k) * 2], loc[(l * p.P + k) * 2 + 1], aw[l * p.P + k], Hl, Wl, lbase, vstride, acc);
         }
     }
     const long o = grp * p.D + c4;
@@ -215,9 +245,11 @@ __device__ __forceinline__ void atomic_add4(float* g, const float4& v) {
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+template <bool FUSED>
 __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn) {
     constexpr int D = 32;
     __shared__ int h_key[MSDA_HASH], h_cnt[MSDA_HASH], h_base[MSDA_HASH];
+    __shared__ float s_loc[FUSED ? 32 * 32 : 1], s_aw[FUSED ? 32 * 16 : 1];     // FUSED: the workgroup's 32 groups' locations / weights
     const int tid = threadIdx.x, j8 = tid & 7, c4 = j8 * 4;
     const int nchunk = (p.Lq + 31) / 32;
     const int chunk = blockIdx.x % nchunk, bm = blockIdx.x / nchunk;
@@ -226,8 +258,37 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
     const bool live = q < p.Lq;
     const long grp = ((long)b * p.Lq + (live ? q : 0)) * p.M + m;
     const int LP = p.L * p.P;
-    const float* loc = p.loc + grp * LP * 2;
-    const float* aw = p.attn + grp * LP;
+    const float* loc = FUSED ? s_loc + (tid >> 3) * 32 : p.loc + grp * LP * 2;
+    const float* aw = FUSED ? s_aw + (tid >> 3) * 16 : p.attn + grp * LP;
+    const long row = (long)b * p.Lq + (live ? q : 0);
+    if (FUSED) {
+        // lane j8 of a group derives samples j8 and j8 + 8 from the projection row (msda_prep_kernel's arithmetic); max and sum over
+        // the group's 8 lanes
+        const float* off = p.offaw + row * p.ld + (long)m * LP * 2;
+        const float* lg = p.offaw + row * p.ld + (long)p.M * LP * 2 + (long)m * LP;
+        const long qr = p.ref_per_image ? row : row % p.Lq;
+        const float* rf = p.ref + qr * p.L * 2;
+        float lv[2], mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int s = j8 + 8 * r; lv[r] = s < LP ? lg[s] : -3.0e38f; mx = fmaxf(mx, lv[r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        float ev[2], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int s = j8 + 8 * r; ev[r] = s < LP ? __expf(lv[r] - mx) : 0.f; sum += ev[r]; }
+        sum = group8_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int s = j8 + 8 * r;
+            if (s < LP) {
+                const int l = s / p.P;
+                const float2 o = *(const float2*)(off + 2 * s);
+                s_loc[(tid >> 3) * 32 + 2 * s] = rf[2 * l] + o.x / (float)p.shapes[2 * l + 1];
+                s_loc[(tid >> 3) * 32 + 2 * s + 1] = rf[2 * l + 1] + o.y / (float)p.shapes[2 * l];
+                s_aw[(tid >> 3) * 16 + s] = ev[r] * inv;
+            }
+        }
+    }
     h_key[tid] = -1; h_cnt[tid] = 0;
     __syncthreads();
 
@@ -357,6 +418,29 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
                 else { keep_w[1] = g_w; keep_h[1] = g_h; keep_a[1] = g_a; }
             }
         }
+    }
+    if (FUSED) {
+        // d(offaw) straight from the group's registers: d(offset) = d(loc) / (W_l, H_l), d(logit) = aw * (d(aw) - sum_s aw d(aw))
+        // (the arithmetic of msda_prep_kernel<true>); lanes write consecutive 4- / 2-byte pieces of the row: coalesced runs
+        float part = 0.f;
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) { const int s = j8 + 8 * rnd; if (s < LP) part += aw[s] * keep_a[rnd]; }
+        const float dot = group8_sum(part);
+        bf16* drow = p.doffaw + row * p.ldd;
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int s = j8 + 8 * rnd;
+            if (s < LP) {
+                const int l = s / p.P;
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 d2;
+                d2[0] = (bf16)(keep_w[rnd] / (float)p.shapes[2 * l + 1]);
+                d2[1] = (bf16)(keep_h[rnd] / (float)p.shapes[2 * l]);
+                *(bf16x2*)(drow + (long)m * LP * 2 + 2 * s) = d2;
+                drow[(long)p.M * LP * 2 + (long)m * LP + s] = (bf16)(aw[s] * (keep_a[rnd] - dot));
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
@@ -507,6 +591,7 @@ static int msda_fill(MsdaP& p, const void* value, int v_dtype, const int64_t* sh
     p.value = value; p.v_f32 = (v_dtype == UENC_F32); p.shapes = shapes; p.level_start = level_start;
     p.loc = loc; p.attn = attn; p.B = B; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
     p.out = nullptr; p.grad_out = nullptr; p.grad_value = nullptr; p.grad_loc = nullptr; p.grad_attn = nullptr;
+    p.offaw = nullptr; p.ld = 0; p.ref = nullptr; p.ref_per_image = 0; p.doffaw = nullptr; p.ldd = 0;
     return UENC_OK;
 }
 
@@ -522,9 +607,9 @@ extern "C" int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int6
     p.out = out; p.out_f32 = (out_dtype == UENC_F32);
     const long threads = (long)B * Lq * M * (D / 4);
     const unsigned grid = (unsigned)((threads + 255) / 256);
-    if (D == 32) hipLaunchKernelGGL(msda_fwd_kernel<8>, dim3(grid), dim3(256), 0, stream, p);
-    else if (D == 16) hipLaunchKernelGGL(msda_fwd_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(msda_fwd_kernel<16>, dim3(grid), dim3(256), 0, stream, p);
+    if (D == 32) hipLaunchKernelGGL((msda_fwd_kernel<8, false>), dim3(grid), dim3(256), 0, stream, p);
+    else if (D == 16) hipLaunchKernelGGL((msda_fwd_kernel<4, false>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((msda_fwd_kernel<16, false>), dim3(grid), dim3(256), 0, stream, p);
     UENC_LAUNCH_RET();
 }
 
@@ -568,7 +653,7 @@ extern "C" int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int6
         bn.rec_hd = (int2*)((char*)workspace + cnt_bytes + (long)B * M * bn.rtot * 16);
         hipError_t e = hipMemsetAsync(bn.count, 0, (size_t)cnt_bytes, stream);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(msda_bwd_bin_kernel, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
+        hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
         if (p.go_f32) hipLaunchKernelGGL(msda_bin_reduce_kernel<true>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
         else hipLaunchKernelGGL(msda_bin_reduce_kernel<false>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
         UENC_LAUNCH_RET();
@@ -578,5 +663,69 @@ extern "C" int uenc_msdeform_attn_bwd(const void* value, int v_dtype, const int6
     if (D == 32) hipLaunchKernelGGL(msda_bwd_kernel<32>, dim3(grid), dim3(256), 0, stream, p);
     else if (D == 64) hipLaunchKernelGGL(msda_bwd_kernel<64>, dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(msda_bwd_kernel<16>, dim3(grid), dim3(256), 0, stream, p);
+    UENC_LAUNCH_RET();
+}
+
+
+// ---- fused form: the sampling locations and attention weights never exist in memory ------------------------------------------
+// What ops/modules/ms_deform_attn.py:99-125 does between its two projection Linears and the native op, inside the op: the row
+// offaw = [sampling_offsets | attention_weights] projection output (one GEMM over the stacked weights), the reference points and the
+// level shapes go in; softmax over the L * P logits and loc = ref + off / (W_l, H_l) happen in registers (forward) / LDS (backward),
+// and the backward returns d(offaw) directly.  Saves, per encoder layer at 1024 x 2048, the 99 MB loc / attn round trip each way
+// and the two glue kernels (uenc_msda_prep_*).  L * P <= 16, D = 32, ld % 2 == 0; the backward needs the binned plan
+// (shapes_host + workspace as for uenc_msdeform_attn_bwd) and returns -1 where that plan does not exist.
+static int msda_fill_fused(MsdaP& p, const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
+                           long ld, const float* ref, int ref_per_image, int B, int S, int M, int D, int L, int Lq, int P) {
+    if (!(offaw && ref)) return UENC_EINVAL;
+    int rc = msda_fill(p, value, v_dtype, shapes, level_start, offaw, offaw, B, S, M, D, L, Lq, P);
+    if (rc != UENC_OK) return rc;
+    if (!(L * P <= 16 && D == 32 && ld >= (long)3 * M * L * P && ld % 2 == 0 && ((uintptr_t)offaw & 7) == 0)) return UENC_EINVAL;
+    p.loc = nullptr; p.attn = nullptr;
+    p.offaw = offaw; p.ld = ld; p.ref = ref; p.ref_per_image = ref_per_image;
+    return UENC_OK;
+}
+
+extern "C" int uenc_msdeform_attn_fused_fwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
+                                            const float* offaw, long ld, const float* ref, int ref_per_image, void* out, int out_dtype,
+                                            int B, int S, int M, int D, int L, int Lq, int P, hipStream_t stream) {
+    MsdaP p;
+    int rc = msda_fill_fused(p, value, v_dtype, shapes, level_start, offaw, ld, ref, ref_per_image, B, S, M, D, L, Lq, P);
+    if (rc != UENC_OK) return rc;
+    UENC_CHECK_ARG(out != nullptr);
+    p.out = out; p.out_f32 = (out_dtype == UENC_F32);
+    const long threads = (long)B * Lq * M * (D / 4);
+    hipLaunchKernelGGL((msda_fwd_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p);
+    UENC_LAUNCH_RET();
+}
+
+extern "C" int uenc_msdeform_attn_fused_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
+                                            const float* offaw, long ld, const float* ref, int ref_per_image, const void* grad_out,
+                                            int go_dtype, float* grad_value, void* doffaw, long ld_doffaw, int B, int S, int M, int D, int L, int Lq, int P,
+                                            const int64_t* shapes_host, void* workspace, long workspace_bytes, hipStream_t stream) {
+    MsdaP p;
+    int rc = msda_fill_fused(p, value, v_dtype, shapes, level_start, offaw, ld, ref, ref_per_image, B, S, M, D, L, Lq, P);
+    if (rc != UENC_OK) return rc;
+    UENC_CHECK_ARG(grad_out && grad_value && doffaw && shapes_host && workspace);
+    UENC_CHECK_ARG(((uintptr_t)grad_out & 15) == 0 && ((uintptr_t)doffaw & 3) == 0 && ld_doffaw >= (long)3 * M * L * P && ld_doffaw % 2 == 0);
+    p.grad_out = grad_out; p.go_f32 = (go_dtype == UENC_F32); p.grad_value = grad_value; p.doffaw = (bf16*)doffaw; p.ldd = ld_doffaw;
+    MsdaBins bn;
+    if (!msda_plan_bins(shapes_host, L, Lq, P, D, bn)) return UENC_EINVAL;
+    { const char* e = getenv("UENC_MSDA_VARIANT"); bn.variant = e ? atoi(e) : 0; }
+    long tot = 0;
+    for (int l = 0; l < L; ++l) tot += shapes_host[2 * l] * shapes_host[2 * l + 1];
+    const long nbins = (long)B * M * bn.nblk;
+    const long cnt_bytes = nbins * MSDA_CNT_STRIDE * 4;
+    const long nchunk = (Lq + 31) / 32;
+    UENC_CHECK_ARG(tot == S && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= cnt_bytes + (long)B * M * bn.rtot * 24);
+    const long nitems = (long)B * M * bn.nwork;
+    UENC_CHECK_ARG(nbins < (1L << 31) && nchunk * B * M < (1L << 31) && (nitems + 3) / 4 < (1L << 31));
+    bn.count = (int*)workspace;
+    bn.rec_w = (float4*)((char*)workspace + cnt_bytes);
+    bn.rec_hd = (int2*)((char*)workspace + cnt_bytes + (long)B * M * bn.rtot * 16);
+    hipError_t e = hipMemsetAsync(bn.count, 0, (size_t)cnt_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
+    if (p.go_f32) hipLaunchKernelGGL(msda_bin_reduce_kernel<true>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
+    else hipLaunchKernelGGL(msda_bin_reduce_kernel<false>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
     UENC_LAUNCH_RET();
 }

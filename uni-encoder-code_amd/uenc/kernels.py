@@ -496,6 +496,49 @@ def msdeform_attn_bwd(value, shapes, level_start, loc, attn, grad_out, shapes_ho
     return gv, gl, ga
 
 
+def _msda_host_plan(shapes_host, B, M, D, L, Lq, P):
+    import ctypes
+    flat = [int(v) for hw in shapes_host for v in hw]
+    assert len(flat) == 2 * L
+    sh = (ctypes.c_int64 * len(flat))(*flat)
+    return sh, int(lib.uenc_msdeform_attn_bwd_workspace_bytes(sh, B, M, D, L, Lq, P))
+
+
+def msdeform_fused_available(shapes_host, B, M, D, L, Lq, P) -> bool:
+    """The fused forward / backward pair (locations and weights derived inside the kernels) needs D = 32, L * P <= 16 and the binned
+    backward's plan; never in the fp32 verification mode (its reference path stays module by module)."""
+    return (not EXACT) and D == 32 and L * P <= 16 and shapes_host is not None and _msda_host_plan(shapes_host, B, M, D, L, Lq, P)[1] > 0
+
+
+def msdeform_attn_fused_fwd(value, shapes, level_start, offaw, ref, L: int, P: int, out_dtype=torch.bfloat16):
+    """value (B, S, M, D), offaw (B * Lq, ld) fp32 = [M][L][P][2] offsets | [M][L * P] logits, ref (B | 1, Lq, L, 2) -> (B, Lq, M * D)."""
+    B, S, M, D = value.shape
+    Lq = ref.shape[1]
+    assert offaw.dtype == torch.float32 and offaw.stride(1) == 1 and offaw.shape[0] == B * Lq and ref.dtype == torch.float32 and ref.is_contiguous()
+    out = torch.empty((B, Lq, M * D), dtype=_odt(out_dtype), device=value.device)
+    check(lib.uenc_msdeform_attn_fused_fwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), offaw.data_ptr(), offaw.stride(0),
+                                           ref.data_ptr(), int(ref.shape[0] != 1), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, stream_ptr()),
+          "msdeform_attn_fused_fwd")
+    return out
+
+
+def msdeform_attn_fused_bwd(value, shapes, level_start, offaw, ref, L: int, P: int, grad_out, shapes_host):
+    """-> grad_value (fp32, B, S, M, D), d(offaw) (B * Lq, 3 M L P) bf16."""
+    B, S, M, D = value.shape
+    Lq = ref.shape[1]
+    assert grad_out.is_contiguous() and grad_out.shape == (B, Lq, M * D)
+    sh, ws_bytes = _msda_host_plan(shapes_host, B, M, D, L, Lq, P)
+    assert ws_bytes > 0
+    ws = _msda_workspace(ws_bytes, value.device)
+    gv = torch.zeros((B, S, M, D), dtype=torch.float32, device=value.device)
+    ncol = 3 * M * L * P
+    doffaw = torch.empty((B * Lq, ncol), dtype=torch.bfloat16, device=value.device)
+    check(lib.uenc_msdeform_attn_fused_bwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), offaw.data_ptr(), offaw.stride(0),
+                                           ref.data_ptr(), int(ref.shape[0] != 1), grad_out.data_ptr(), dt(grad_out), gv.data_ptr(), doffaw.data_ptr(), doffaw.stride(0),
+                                           B, S, M, D, L, Lq, P, sh, ws.data_ptr(), ws_bytes, stream_ptr()), "msdeform_attn_fused_bwd")
+    return gv, doffaw
+
+
 def attn_mask(logits: torch.Tensor, size) -> torch.Tensor:
     """(B, Q, Hi, Wi) fp32 mask logits -> (B, Q, Ho*Wo) bool, True = blocked; fully blocked rows are cleared."""
     B, Q, Hi, Wi = logits.shape

@@ -875,8 +875,16 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         q16 = K.add_cast_bf16(x, posc.reshape(-1, C))
         value = K.gemm_nt(x16, CACHE.mat(wv), bias=bv.detach())                                   # (M, C) bf16
         offaw = K.gemm_nt(q16, CACHE.cat(woff, waw), bias=CACHE.catvec(boff, baw), out_dtype=F32)   # (M, 3 nH L P) fp32
+        shapes_host = _host_shapes(shapes)
+        # fused: sampling locations / softmaxed weights are derived inside the attention kernels from the projection row (no loc / aw tensors,
+        # no glue kernels); UENC_MSDA_FUSED=0 keeps the module-by-module pair (A/B, and the form every other configuration takes)
+        fused = os.environ.get("UENC_MSDA_FUSED", "1") != "0" and K.msdeform_fused_available(shapes_host, B, nH, D, L, S, nP)
+        # (the forward keeps the glue kernel + core pair: the fused forward measured 5 % SLOWER at the pixel decoder's size, the fused
+        # backward 7-8 % faster -- tools/msda_fused_bench.py; it recomputes locations / weights from the saved projection row)
         loc, aw = K.msda_prep_fwd(offaw, ref, shapes, B, S, nH, L, nP)
         att = K.msdeform_attn_fwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, out_dtype=BF16).view(M, C)
+        if fused:
+            loc, aw = offaw, ref
         if drop is None or K.EXACT:
             assert drop is None, "the fp32 verification mode has no dropout path"
             h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
@@ -906,7 +914,8 @@ class DeformEncoderLayerFn(torch.autograd.Function):
                               wv, bv, woff, boff, waw, baw, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2)
         ctx.geom = (B, S, C, nH, nP)
         ctx.drop = drop
-        ctx.shapes_host = _host_shapes(shapes)
+        ctx.shapes_host = shapes_host
+        ctx.fused = fused               # then (loc, aw) hold (offaw, ref)
         return out.view(B, S, C)
 
     @staticmethod
@@ -942,9 +951,12 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         datt = K.gemm_nt(dh1_16, CACHE.mat_t(wo))                                                  # (M, C) bf16
         if train:
             _tn(dh1_16, att, grad_buf(wo), grad_buf(bo), (wo, bo))
-        gv, gl, ga = K.msdeform_attn_bwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, datt.view(B, S, C), ctx.shapes_host)
         ncol = 3 * nH * L * nP
-        doffaw = K.msda_prep_bwd(gl, ga, aw, shapes, ncol)                                         # (M, ncol) bf16
+        if ctx.fused:
+            gv, doffaw = K.msdeform_attn_fused_bwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, L, nP, datt.view(B, S, C), ctx.shapes_host)
+        else:
+            gv, gl, ga = K.msdeform_attn_bwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, datt.view(B, S, C), ctx.shapes_host)
+            doffaw = K.msda_prep_bwd(gl, ga, aw, shapes, ncol)                                     # (M, ncol) bf16
         gv16 = K.cast_bf16(gv.view(M, C))
         dsrc = K.gemm_nt(doffaw, CACHE.cat(woff, waw, transposed=True), epilogue=K.EPI_RESIDUAL, aux=dh1, out_dtype=F32)
         dsrc = K.gemm_nt(gv16, CACHE.mat_t(wv), epilogue=K.EPI_RESIDUAL, aux=dsrc, out=dsrc)        # dh1 + dq + dvalue-in
