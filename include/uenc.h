@@ -182,7 +182,15 @@ int uenc_layernorm_fwd(const void* x, int x_dtype, const void* res, int res_dtyp
  * workgroups' dgamma / dbeta partials are stored and summed by a second small kernel instead of added atomically. */
 int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats, const float* gamma,
                        const float* dres, void* dx, int dx_dtype, float* dgamma, float* dbeta, long M, int C, void* dx16,
-                       float* part_ws, uenc_stream_t stream);
+                       float* part_ws, int defer_param_sums, uenc_stream_t stream);
+/* Deferred parameter sums.  With part_ws and defer_param_sums != 0 the block partials of dgamma / dbeta stay in part_ws -- [nblk][2][C]
+ * floats, nblk = uenc_layernorm_bwd_blocks(M, C) (0: the pass adds its few block sums itself and nothing is deferred) -- and NO reduction is
+ * launched; the caller keeps part_ws untouched and later sums the partials of many passes in ONE launch:
+ *   table: n descriptors in DEVICE memory, 40 bytes each { const float* part; float* dgamma; float* dbeta; int nblk, C, group_begin, pad; },
+ *   group_begin = exclusive prefix sum of ceil(2C / 64), total_groups = the full sum; dgamma / dbeta are accumulated.
+ * (A training step leaves ~70 such reductions of a few MB each: 10 us launches for 2 us of work.) */
+int uenc_layernorm_bwd_blocks(long M, int C);
+int uenc_ln_param_grouped(const void* table, int n, int total_groups, uenc_stream_t stream);
 /* PatchMerging's pad-to-even + 2x2 strided gather + concat (order (0,0), (1,0), (0,1), (1,1)) + LayerNorm(4C) as one pass
  * (reference model/modeling/backbone/swin.py:311-334; the 4C -> 2C reduction GEMM follows): x (B, H, W, C) fp32 ->
  * y (B * ceil(H/2) * ceil(W/2), 4C) bf16, stats (rows, 2).  Backward: dy (rows, 4C) bf16 | fp32 -> dx (B, H, W, C) fp32 written
@@ -190,7 +198,8 @@ int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype,
 int uenc_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, void* y, float* stats, int B, int H, int W,
                             int C, float eps, uenc_stream_t stream);
 int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* stats, const float* gamma, float* dx,
-                            float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, uenc_stream_t stream);
+                            float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, int defer_param_sums,
+                            uenc_stream_t stream);          /* rows M = B * ceil(H/2) * ceil(W/2), width 4C for uenc_layernorm_bwd_blocks */
 
 /* ---- shifted-window attention (head_dim 32, window <= 12) ---------------------------------------------
  * Replaces F.pad -> torch.roll -> window_partition -> WindowAttention core -> window_reverse -> roll -> crop,
@@ -210,7 +219,13 @@ int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bia
 long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws);
 int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
                          const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
-                         int B, int H, int W, int C, int nH, int ws, int shift, float scale, uenc_stream_t stream);
+                         int B, int H, int W, int C, int nH, int ws, int shift, float scale, int defer_dtable, uenc_stream_t stream);
+/* defer_dtable != 0: dqkv and dbias_pad as above, but the relative-position-table gradient is NOT reduced: dS_ws keeps the dense partials
+ * [nH][G][ntiles][NP * 16] (G = uenc_window_attn_bwd_groups(...), ntiles = NP / 16) and the caller, keeping dS_ws untouched, reduces the
+ * partials of many passes in one launch: table = n descriptors in DEVICE memory, 40 bytes each
+ * { const float* wsd; float* dtab; int G, nH, ws, ntiles, blk_begin, pad; }, blk_begin = exclusive prefix sum of nH * ntiles. */
+int uenc_window_attn_bwd_groups(int B, int H, int W, int nH, int ws);
+int uenc_window_attn_dtable_grouped(const void* table, int n, int total_blocks, uenc_stream_t stream);
 
 /* ---- multi-scale deformable attention: the reference's native op ---------------------------------------
  * ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)

@@ -1,0 +1,9 @@
+set -x
+timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "swin_block or layer_norm or patch_merg or full_model or training" > gpurun_out/r3_defer_tests2.log 2>&1
+echo "rc=$?" >> gpurun_out/r3_defer_tests2.log; tail -3 gpurun_out/r3_defer_tests2.log
+grep -q "rc=0" gpurun_out/r3_defer_tests2.log || exit 1
+for v in 0 1 0 1 0 1; do
+  UENC_DEFER_SMALL=$v timeout -k 10 300 python bench.py --steps 10 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('DEFER_SMALL=$v', d['ms_per_step'], d['step_ms'])" >> gpurun_out/r3_defer_ab2.txt
+done
+cat gpurun_out/r3_defer_ab2.txt

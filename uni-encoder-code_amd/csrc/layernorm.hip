@@ -298,30 +298,47 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restri
     }
 }
 
-static int ln_bwd_launch(LnBwd& p, float* part_ws, hipStream_t stream);
+static int ln_bwd_launch(LnBwd& p, float* part_ws, int defer, hipStream_t stream);
 
 extern "C" int uenc_layernorm_bwd(const void* dy, int dy_dtype, const void* h, int h_dtype, const float* stats,
                                   const float* gamma, const float* dres, void* dx, int dx_dtype, float* dgamma,
-                                  float* dbeta, long M, int C, void* dx16, float* part_ws, hipStream_t stream) {
+                                  float* dbeta, long M, int C, void* dx16, float* part_ws, int defer_param_sums, hipStream_t stream) {
     UENC_CHECK_ARG(dy && h && stats && gamma && dx && M > 0 && C > 0 && C % 4 == 0 && C <= 6144);
     UENC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     LnBwd p;
     p.dy = dy; p.dy_f32 = (dy_dtype == UENC_F32); p.h = h; p.h_f32 = (h_dtype == UENC_F32);
     p.stats = (const float2*)stats; p.gamma = gamma; p.dres = dres; p.dx = dx; p.dx_f32 = (dx_dtype == UENC_F32); p.dx16 = (bf16*)dx16;
     p.dgamma = dgamma; p.dbeta = dbeta; p.M = M; p.C = C; p.mgH = p.mgW = p.mgC = 0;
-    return ln_bwd_launch(p, part_ws, stream);
+    return ln_bwd_launch(p, part_ws, defer_param_sums, stream);
 }
 
-static int ln_bwd_launch(LnBwd& p, float* part_ws, hipStream_t stream) {
-    const long M = p.M; const int C = p.C;
-    float* dgamma = p.dgamma; float* dbeta = p.dbeta;
+// workgroups of a LayerNorm backward over M rows, and whether their dgamma / dbeta partials are STORED (then summed by a second kernel)
+static long ln_bwd_blocks(long M, int C, bool with_ws, bool* stored) {
     long blocks = (M + 3) / 4;
-    long cap = (part_ws != nullptr && dgamma != nullptr) ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
+    long cap = with_ws ? 2048 : 1024;      // part_ws: (2048, 2, C) floats
     { const char* e = getenv("UENC_LN_BWD_BLOCKS"); if (e && atoi(e) >= 64 && atoi(e) <= 2048) cap = atoi(e); }     // tuning knob
     if (blocks > cap) blocks = cap;
     // few rows (the decoder's 300-token LayerNorms): the handful of block partials goes straight to dgamma / dbeta by atomics,
     // a second launch would cost more than it saves
-    p.part = (dgamma != nullptr && blocks * 2 * C > 131072) ? part_ws : nullptr;
+    *stored = with_ws && blocks * 2 * C > 131072;
+    return blocks;
+}
+
+// Rows of stored partials ([nblk][2][C] floats) a LayerNorm backward over (M, C) with a scratch buffer writes; 0: it adds its few block sums
+// atomically and nothing is left to reduce.  For callers that defer the reduction (defer_param_sums) and run uenc_ln_param_grouped later.
+extern "C" int uenc_layernorm_bwd_blocks(long M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    bool stored = false;
+    const long b = ln_bwd_blocks(M, C, true, &stored);
+    return stored ? (int)b : 0;
+}
+
+static int ln_bwd_launch(LnBwd& p, float* part_ws, int defer, hipStream_t stream) {
+    const long M = p.M; const int C = p.C;
+    float* dgamma = p.dgamma; float* dbeta = p.dbeta;
+    bool stored = false;
+    const long blocks = ln_bwd_blocks(M, C, part_ws != nullptr && dgamma != nullptr, &stored);
+    p.part = stored ? part_ws : nullptr;
     const int nv = (C + 255) / 256;
     const size_t shm = (size_t)(C > 2048 ? 1 : 4) * 2 * C * sizeof(float);      // <= 64 KB
     dim3 grid((unsigned)blocks), block(256);
@@ -331,8 +348,44 @@ static int ln_bwd_launch(LnBwd& p, float* part_ws, hipStream_t stream) {
     else if (nv <= 8) LN_LAUNCH(bwd, 8, grid, block, shm, stream, p);
     else if (nv <= 16) LN_LAUNCH(bwd, 16, grid, block, shm, stream, p);
     else LN_LAUNCH(bwd, 24, grid, block, shm, stream, p);
-    if (p.part != nullptr)
+    if (p.part != nullptr && !defer)
         hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((2 * C + 63) / 64, 16), dim3(256), 0, stream, (const float*)p.part, (int)blocks, C, dgamma, dbeta);
+    UENC_LAUNCH_RET();
+}
+
+// Grouped form of ln_bwd_param_kernel: the dgamma / dbeta sums of MANY LayerNorm backward passes in one launch.  A backward pass leaves
+// ~70 of these reductions (a few MB of block partials each); alone each is a 10 us launch for ~2 us of work.  Their results are needed
+// only by the optimiser, so the callers park the partials (uenc_layernorm_bwd(..., defer_param_sums = 1)) and run this once.
+// table: n descriptors in device memory, 40 bytes each: { const float* part; float* dgamma; float* dbeta; int nblk, C, group_begin, pad; }
+// group_begin = exclusive prefix sum of ceil(2C / 64); total_groups = the full sum.
+struct LnParamDesc { const float* part; float* dgamma; float* dbeta; int nblk, C, group_begin, pad; };
+__global__ __launch_bounds__(256) void ln_param_grouped_kernel(const LnParamDesc* __restrict__ table, int n) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = n - 1;
+    const int grp = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].group_begin <= grp) lo = mid; else hi = mid - 1;
+    }
+    const LnParamDesc d = table[lo];
+    const int C = d.C, nblk = d.nblk;
+    const int col = (grp - d.group_begin) * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;      // col over [0, 2C)
+    const int per = (nblk + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float acc = 0.f;
+    if (col < 2 * C)
+        for (int b = b0 + r; b < b1; b += 4) acc += d.part[(long)b * 2 * C + col];
+    red[r][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (r == 0 && col < 2 * C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(col < C ? d.dgamma + col : d.dbeta + (col - C), v);
+    }
+}
+
+extern "C" int uenc_ln_param_grouped(const void* table, int n, int total_groups, hipStream_t stream) {
+    UENC_CHECK_ARG(table && n > 0 && total_groups > 0 && ((uintptr_t)table & 7) == 0);
+    static_assert(sizeof(LnParamDesc) == 40, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(ln_param_grouped_kernel, dim3((unsigned)total_groups, 16), dim3(256), 0, stream, (const LnParamDesc*)table, n);
     UENC_LAUNCH_RET();
 }
 
@@ -352,12 +405,13 @@ extern "C" int uenc_patch_merge_ln_fwd(const float* x, const float* gamma, const
 }
 
 extern "C" int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const float* stats, const float* gamma, float* dx,
-                                       float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, hipStream_t stream) {
+                                       float* dgamma, float* dbeta, float* part_ws, int B, int H, int W, int C, int defer_param_sums,
+                                       hipStream_t stream) {
     UENC_CHECK_ARG(dy && x && stats && gamma && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && 4 * C <= 6144);
     UENC_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
     LnBwd p;
     p.dy = dy; p.dy_f32 = (dy_dtype == UENC_F32); p.h = x; p.h_f32 = 1; p.stats = (const float2*)stats; p.gamma = gamma; p.dres = nullptr;
     p.dx = dx; p.dx_f32 = 1; p.dx16 = nullptr; p.dgamma = dgamma; p.dbeta = dbeta;
     p.M = (long)B * ((H + 1) / 2) * ((W + 1) / 2); p.C = 4 * C; p.mgH = H; p.mgW = W; p.mgC = C;
-    return ln_bwd_launch(p, part_ws, stream);
+    return ln_bwd_launch(p, part_ws, defer_param_sums, stream);
 }

@@ -547,6 +547,52 @@ __global__ __launch_bounds__(256) void wattn_dtable_kernel(const float* __restri
     }
 }
 
+// Grouped form: the table gradients of MANY window-attention backward passes in one launch (24 per step for Swin-L, ~19 us each alone).
+// table: n descriptors in device memory, 40 bytes each: { const float* wsd; float* dtab; int G, nH, ws, ntiles, blk_begin, pad; }
+// blk_begin = exclusive prefix sum of nH * ntiles; total_blocks = the full sum.  wsd = the dense dS partials uenc_window_attn_bwd wrote
+// (defer_dtable = 1 leaves them un-reduced); they must stay untouched until this runs.
+struct DtableDesc { const float* wsd; float* dtab; int G, nH, ws, ntiles, blk_begin, pad; };
+__global__ __launch_bounds__(256) void wattn_dtable_grouped_kernel(const DtableDesc* __restrict__ table, int n) {
+    __shared__ __attribute__((aligned(16))) float slab[9 * 16 * 16];       // NP * 16 for NTILES <= 9
+    int lo = 0, hi = n - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk_begin <= blk) lo = mid; else hi = mid - 1;
+    }
+    const DtableDesc d = table[lo];
+    const int NT = d.ntiles, NP = NT * 16, SLAB = NP * 16;
+    const int local = blk - d.blk_begin;
+    const int head = local / NT, qt = local - head * NT;
+    for (int e = threadIdx.x; e < SLAB / 4; e += 256) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < d.G; ++g) a += *(const f32x4*)(d.wsd + (((long)head * d.G + g) * NT + qt) * SLAB + e * 4);
+        *(f32x4*)(slab + e * 4) = a;
+    }
+    __syncthreads();
+    const int ws = d.ws, N = ws * ws, T1 = 2 * ws - 1;
+    for (int t = threadIdx.x; t < T1 * T1; t += 256) {
+        const int dy = t / T1 - (ws - 1), dx = t % T1 - (ws - 1);
+        float acc = 0.f;
+        for (int fr = 0; fr < 16; ++fr) {
+            const int q = qt * 16 + fr;
+            if (q >= N) break;
+            const int ky = q / ws - dy, kx = q % ws - dx;
+            if (ky < 0 || ky >= ws || kx < 0 || kx >= ws) continue;
+            const int key = ky * ws + kx;
+            acc += slab[((key >> 4) * 64 + ((key & 15) >> 2) * 16 + fr) * 4 + (key & 3)];
+        }
+        if (acc != 0.f) atomicAdd(d.dtab + (long)t * d.nH + head, acc);
+    }
+}
+
+extern "C" int uenc_window_attn_dtable_grouped(const void* table, int n, int total_blocks, hipStream_t stream) {
+    UENC_CHECK_ARG(table && n > 0 && total_blocks > 0 && ((uintptr_t)table & 7) == 0);
+    static_assert(sizeof(DtableDesc) == 40, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(wattn_dtable_grouped_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, (const DtableDesc*)table, n);
+    UENC_LAUNCH_RET();
+}
+
 // expanded relative-position bias: table ((2ws-1)^2, nH) fp32 -> log2(e)-scaled bias_q [h][q][key], bias_k [h][key][q]
 __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ bias_q, float* __restrict__ bias_k,
                                      int nH, int ws, int NP) {
@@ -610,7 +656,7 @@ static int wattn_bwd_groups(int nWinTotal, int nH, int ntiles) {
 }
 
 template <int NT>
-static int launch_bwd(const WAttn& p, float* dtab, hipStream_t stream) {
+static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t stream) {
     using Cf = WCfg<NT>;
     constexpr int NK2 = Cf::NK2;
     const int G = wattn_bwd_groups(p.nWinTotal, p.nH, NT);
@@ -624,8 +670,9 @@ static int launch_bwd(const WAttn& p, float* dtab, hipStream_t stream) {
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
     hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), shm, stream, p, G);
-    hipLaunchKernelGGL(wattn_dtable_kernel<NT>, dim3((unsigned)(p.nH * NT)), dim3(256), 0, stream, (const float*)p.dtab_ws, dtab, G,
-                       p.nH, p.ws);
+    if (!defer_dtable)
+        hipLaunchKernelGGL(wattn_dtable_kernel<NT>, dim3((unsigned)(p.nH * NT)), dim3(256), 0, stream, (const float*)p.dtab_ws, dtab, G,
+                           p.nH, p.ws);
     return UENC_OK;
 }
 
@@ -656,6 +703,13 @@ extern "C" int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const
     UENC_LAUNCH_RET();
 }
 
+// Workgroup groups per head of uenc_window_attn_bwd (the G of its dense dS partials [nH][G][ntiles][NP * 16]); ntiles = uenc_window_attn_np(ws) / 16.
+extern "C" int uenc_window_attn_bwd_groups(int B, int H, int W, int nH, int ws) {
+    if (!(B > 0 && H > 0 && W > 0 && nH > 0 && ws >= 1 && ws <= 12)) return 0;
+    const long nwin = (long)B * ((H + ws - 1) / ws) * ((W + ws - 1) / ws);
+    return wattn_bwd_groups((int)nwin, nH, wattn_ntiles(ws));
+}
+
 // Scratch floats for the dense dS partials of uenc_window_attn_bwd.
 extern "C" long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws) {
     if (!(B > 0 && H > 0 && W > 0 && nH > 0 && ws >= 1 && ws <= 12)) return 0;
@@ -669,7 +723,7 @@ extern "C" long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int 
 // uenc_window_attn_bwd_ws_floats() floats.
 extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
                                     const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
-                                    int B, int H, int W, int C, int nH, int ws, int shift, float scale, hipStream_t stream) {
+                                    int B, int H, int W, int C, int nH, int ws, int shift, float scale, int defer_dtable, hipStream_t stream) {
     WAttn p;
     int rc = fill_params(p, qkv, qkv_bias, bias_q, bias_k, B, H, W, C, nH, ws, shift, scale);
     if (rc != UENC_OK) return rc;
@@ -677,7 +731,7 @@ extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const
     UENC_CHECK_ARG((((uintptr_t)o_saved | (uintptr_t)d_out | (uintptr_t)dqkv | (uintptr_t)dS_ws) & 15) == 0);
     p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab_ws = dS_ws;
     p.dpad = dbias_pad;
-#define CALL(NT) { rc = launch_bwd<NT>(p, dtable, stream); if (rc != UENC_OK) return rc; }
+#define CALL(NT) { rc = launch_bwd<NT>(p, dtable, defer_dtable, stream); if (rc != UENC_OK) return rc; }
     WATTN_DISPATCH(wattn_ntiles(ws), CALL)
 #undef CALL
     UENC_LAUNCH_RET();

@@ -50,7 +50,11 @@ _SIGNATURES = {
     "uenc_gemm_tn_grouped": [c_p, c_i, c_i, c_i, ctypes.c_double, c_p],
     "uenc_gemm_tn_grouped_small": [c_p, c_i, c_i, ctypes.c_double, c_p],
     "uenc_layernorm_fwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p, c_p],
-    "uenc_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p, c_p, c_p],
+    "uenc_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p, c_p, c_i, c_p],
+    "uenc_layernorm_bwd_blocks": [c_l, c_i],
+    "uenc_ln_param_grouped": [c_p, c_i, c_i, c_p],
+    "uenc_window_attn_bwd_groups": [c_i, c_i, c_i, c_i, c_i],
+    "uenc_window_attn_dtable_grouped": [c_p, c_i, c_i, c_p],
     "uenc_msdeform_attn_fwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_msdeform_attn_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p],
     "uenc_msdeform_attn_bwd_workspace_bytes": [c_p, c_i, c_i, c_i, c_i, c_i, c_i],
@@ -67,7 +71,7 @@ _SIGNATURES = {
     "uenc_postproc_panoptic_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_postproc_panoptic_label": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_patch_merge_ln_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
-    "uenc_patch_merge_ln_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "uenc_patch_merge_ln_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_im2col3x3_s2": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_col2im3x3_s2": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "uenc_na2d_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
@@ -81,7 +85,7 @@ _SIGNATURES = {
     "uenc_mha_f32_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_mha_f32_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
                          c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
-    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
 }
 
 

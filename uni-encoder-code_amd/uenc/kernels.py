@@ -238,9 +238,11 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, r
 
 def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, *,
                   dres: Optional[torch.Tensor] = None, dgamma: Optional[torch.Tensor] = None,
-                  dbeta: Optional[torch.Tensor] = None, dx_dtype=torch.float32, twin: Optional[list] = None) -> torch.Tensor:
+                  dbeta: Optional[torch.Tensor] = None, dx_dtype=torch.float32, twin: Optional[list] = None,
+                  defer: Optional["SmallReductions"] = None) -> torch.Tensor:
     """dx = LN'(dy) [+ dres]; dgamma / dbeta are accumulated in place (fp32).  twin: a list that receives the bf16 copy of an
-    fp32 dx, written in the same pass."""
+    fp32 dx, written in the same pass.  defer: a SmallReductions queue -- the dgamma / dbeta block partials are parked in a private
+    buffer and summed by the queue's next flush (one launch for all parked passes) instead of by a launch of their own."""
     C = h.shape[-1]
     M = h.numel() // C
     assert dy.is_contiguous() and h.is_contiguous() and dy.shape == h.shape
@@ -255,9 +257,9 @@ def layernorm_bwd(dy: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, gamma:
     if twin is not None and dx_dtype == torch.float32:
         dx16 = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
         twin.append(dx16)
-    part = _scratch("ln_bwd", 2048 * 2 * C * 4, h.device) if dgamma is not None else None
+    part, deferred = _ln_part(M, C, dgamma, dbeta, h.device, defer)
     check(lib.uenc_layernorm_bwd(dy.data_ptr(), dt(dy), h.data_ptr(), dt(h), stats.data_ptr(), gamma.data_ptr(),
-                                 ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, ptr(dx16), ptr(part), stream_ptr()),
+                                 ptr(dres), dx.data_ptr(), dt(dx), ptr(dgamma), ptr(dbeta), M, C, ptr(dx16), ptr(part), int(deferred), stream_ptr()),
           "layernorm_bwd")
     if twin_exact is not None and dx_dtype == torch.float32:
         twin_exact.append(dx)
@@ -358,14 +360,98 @@ def patch_merge_ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     return y, stats
 
 
-def patch_merge_ln_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, dgamma=None, dbeta=None) -> torch.Tensor:
+def patch_merge_ln_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, dgamma=None, dbeta=None,
+                       defer: Optional["SmallReductions"] = None) -> torch.Tensor:
     B, H, W, C = x.shape
     assert dy.is_contiguous() and dy.shape[-1] == 4 * C
     dx = torch.empty_like(x)
-    part = _scratch("ln_bwd", 2048 * 2 * 4 * C * 4, x.device) if dgamma is not None else None
+    M = B * ((H + 1) // 2) * ((W + 1) // 2)
+    part, deferred = _ln_part(M, 4 * C, dgamma, dbeta, x.device, defer)
     check(lib.uenc_patch_merge_ln_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), dx.data_ptr(), ptr(dgamma),
-                                      ptr(dbeta), ptr(part), B, H, W, C, stream_ptr()), "patch_merge_ln_bwd")
+                                      ptr(dbeta), ptr(part), B, H, W, C, int(deferred), stream_ptr()), "patch_merge_ln_bwd")
     return dx
+
+
+class SmallReductions:
+    """Parameter-gradient reductions that nothing in the backward pass waits for, parked and launched together.
+
+    A LayerNorm backward leaves [blocks][2][C] partial sums of dgamma / dbeta, a window-attention backward dense dS partials of its
+    relative-position table; summing them is ~2 us of work in a ~10 / ~19 us launch, ~70 + 24 times per step.  Only the optimiser (and the
+    gradient all-reduce) reads the results, so the partials stay in private buffers and ONE grouped launch per kind sums them when the
+    queue is flushed (ops.WgradQueue.flush: with the deferred weight-gradient groups, and at the end of every backward pass)."""
+    _LN = [("part", "<u8"), ("dgamma", "<u8"), ("dbeta", "<u8"), ("nblk", "<i4"), ("C", "<i4"), ("begin", "<i4"), ("pad", "<i4")]
+    _DT = [("wsd", "<u8"), ("dtab", "<u8"), ("G", "<i4"), ("nH", "<i4"), ("ws", "<i4"), ("ntiles", "<i4"), ("begin", "<i4"), ("pad", "<i4")]
+
+    CHUNK = 64 << 20          # floats' worth of bytes per arena chunk
+
+    def __init__(self):
+        self.ln, self.dt, self.keep = [], [], []
+        self._chunks, self._cur, self._off = [], 0, 0        # bump-allocated arena for the parked partials, reused every step
+
+    def alloc(self, nfloats: int, device) -> torch.Tensor:
+        """A private fp32 buffer that stays untouched until the next flush.  Bump-allocated from chunks that persist across steps (the
+        ~1 GB of partials a backward pass parks would otherwise go through the caching allocator ~140 times per step)."""
+        nbytes = (nfloats * 4 + 255) // 256 * 256
+        while True:
+            if self._cur < len(self._chunks):
+                c = self._chunks[self._cur]
+                if c.device == device and self._off + nbytes <= c.numel():
+                    out = c[self._off:self._off + nfloats * 4].view(torch.float32)
+                    self._off += nbytes
+                    return out
+                self._cur += 1
+                self._off = 0
+                continue
+            self._chunks.append(torch.empty(max(self.CHUNK, nbytes), dtype=torch.uint8, device=device))
+
+    def __bool__(self):
+        return bool(self.ln or self.dt)
+
+    def add_ln(self, part, dgamma, dbeta, nblk: int, C: int):
+        self.ln.append((part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), nblk, C))
+        self.keep.append((part, dgamma, dbeta))
+
+    def add_dtable(self, wsd, dtab, G: int, nH: int, ws: int, ntiles: int):
+        self.dt.append((wsd.data_ptr(), dtab.data_ptr(), G, nH, ws, ntiles))
+        self.keep.append((wsd, dtab))
+
+    def clear(self):
+        self.ln, self.dt, self.keep = [], [], []
+        self._cur, self._off = 0, 0           # stream order: whatever is parked next is written after the reductions launched above
+
+    def flush(self):
+        import numpy as np
+        dev = self.keep[0][0].device if self.keep else None
+        if self.ln:
+            desc = np.zeros(len(self.ln), dtype=self._LN)
+            begin = 0
+            for i, (part, dg, db, nblk, C) in enumerate(self.ln):
+                desc[i] = (part, dg, db, nblk, C, begin, 0)
+                begin += -(-2 * C // 64)
+            tab = torch.from_numpy(desc.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
+            check(lib.uenc_ln_param_grouped(tab.data_ptr(), len(self.ln), begin, stream_ptr()), "ln_param_grouped")
+        if self.dt:
+            desc = np.zeros(len(self.dt), dtype=self._DT)
+            begin = 0
+            for i, (wsd, dtab, G, nH, ws, nt) in enumerate(self.dt):
+                desc[i] = (wsd, dtab, G, nH, ws, nt, begin, 0)
+                begin += nH * nt
+            tab = torch.from_numpy(desc.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
+            check(lib.uenc_window_attn_dtable_grouped(tab.data_ptr(), len(self.dt), begin, stream_ptr()), "window_attn_dtable_grouped")
+        self.clear()
+
+
+def _ln_part(M: int, C: int, dgamma, dbeta, device, defer):
+    """Scratch for a LayerNorm backward's dgamma / dbeta block partials: the shared buffer (the pass reduces them itself), or -- deferred --
+    a private one registered with the queue.  -> (buffer | None, deferred?)"""
+    if dgamma is None:
+        return None, False
+    nblk = int(lib.uenc_layernorm_bwd_blocks(M, C)) if defer is not None else 0
+    if nblk > 0:
+        part = defer.alloc(nblk * 2 * C, device)
+        defer.add_ln(part, dgamma, dbeta, nblk, C)
+        return part, True
+    return _scratch("ln_bwd", 2048 * 2 * C * 4, device), False
 
 
 def relpos_expand(table: torch.Tensor, ws: int):
@@ -416,7 +502,7 @@ def _scratch(tag: str, nbytes: int, device) -> torch.Tensor:
 
 
 def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, shift: int, scale: float,
-                    dtable: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None):
+                    dtable: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, defer: Optional[SmallReductions] = None):
     """-> dqkv (B,H,W,3C).  The two parameter gradients are ACCUMULATED by the kernels into `dtable` ((2ws-1)^2, nH) fp32 -- the
     relative-position table's .grad -- and `dbias` (3C) fp32 -- the share of qkv.bias.grad that flows through padding slots; when
     a buffer is not given (no training) the contribution goes to scratch."""
@@ -441,10 +527,14 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
     assert o_saved.dtype == torch.bfloat16 and o_saved.is_contiguous()
     dqkv = torch.empty_like(qkv)
     nws = int(lib.uenc_window_attn_bwd_ws_floats(B, H, W, nH, ws))
-    wsbuf = _scratch("wattn_dS", nws * 4, qkv.device)                    # dense dS partials (internal)
+    if defer is not None:                                                # the table gradient is reduced by the queue's grouped launch
+        wsbuf = defer.alloc(nws, qkv.device)
+        defer.add_dtable(wsbuf, dtable, int(lib.uenc_window_attn_bwd_groups(B, H, W, nH, ws)), nH, ws, int(lib.uenc_window_attn_np(ws)) // 16)
+    else:
+        wsbuf = _scratch("wattn_dS", nws * 4, qkv.device)                # dense dS partials (internal)
     check(lib.uenc_window_attn_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), bias_k.data_ptr(),
                                    o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(), dtable.data_ptr(), dbias.data_ptr(),
-                                   B, H, W, C, nH, ws, shift, float(scale), stream_ptr()), "window_attn_bwd")
+                                   B, H, W, C, nH, ws, shift, float(scale), int(defer is not None), stream_ptr()), "window_attn_bwd")
     return dqkv
 
 

@@ -281,7 +281,7 @@ class WgradQueue:
                 pass
 
     def busy(self) -> bool:
-        return bool(self.notify or self.items[256] or self.items[128] or self.small_items)
+        return bool(self.notify or self.items[256] or self.items[128] or self.small_items or SMALLQ)
 
     def add(self, dy, x, gw, gb, notify=(), first=False, alpha: float = 1.0):
         M, N, Kd = dy.shape[0], dy.shape[1], x.shape[1]
@@ -332,6 +332,7 @@ class WgradQueue:
         self.pending = {256: [], 128: []}
         self.items = {256: 0, 128: 0}
         self.small, self.small_items, self.notify = [], 0, []
+        SMALLQ.clear()
         self.callback_armed = False
         self.written = set()
         self.stores = {}
@@ -373,12 +374,53 @@ class WgradQueue:
             check(lib.uenc_gemm_tn_grouped_small(tab.data_ptr(), len(self.small), begin, flops, stream_ptr()), "gemm_tn_grouped_small")
             self.small = []
             self.small_items = 0
+        if SMALLQ:
+            SMALLQ.flush()                      # parked LayerNorm / position-table partial sums: one grouped launch per kind
         if self.notify:
             params, self.notify = self.notify, []
             _notify(*params)
 
 
 WGRADS = WgradQueue()
+
+# Small parameter-gradient reductions (LayerNorm dgamma / dbeta block partials, relative-position-table partials) parked during the backward
+# pass and summed by one grouped launch per kind when the weight-gradient queue is flushed (K.SmallReductions).  UENC_DEFER_SMALL=0: every
+# pass reduces its own partials, as before (A/B).
+SMALLQ = K.SmallReductions()
+_DEFER_SMALL = os.environ.get("UENC_DEFER_SMALL", "1") != "0"
+
+
+def _defer():
+    return SMALLQ if (_DEFER_SMALL and WGRADS.enabled and not K.EXACT) else None
+
+
+def _after_deferred():
+    """A reduction was parked: make sure the end-of-backward flush runs; outside a backward pass (no engine callback) flush right away."""
+    if SMALLQ:
+        WGRADS._arm()
+        if not WGRADS.callback_armed:
+            WGRADS.flush()
+
+
+def _ln_bwd(*a, **k):
+    k.setdefault("defer", _defer())
+    r = K.layernorm_bwd(*a, **k)
+    _after_deferred()
+    return r
+
+
+def _pm_ln_bwd(*a, **k):
+    k.setdefault("defer", _defer())
+    r = K.patch_merge_ln_bwd(*a, **k)
+    _after_deferred()
+    return r
+
+
+def _wattn_bwd(*a, **k):
+    k.setdefault("defer", _defer() if k.get("dtable") is not None else None)
+    r = K.window_attn_bwd(*a, **k)
+    _after_deferred()
+    return r
 
 
 def begin_step(fresh_grads: bool = False):
@@ -643,10 +685,10 @@ class LayerNormFn(torch.autograd.Function):
         dg = grad_buf(gamma) if gamma.requires_grad else None
         db = grad_buf(beta) if gamma.requires_grad else None
         tw = [] if h.numel() // h.shape[-1] >= _BIG_M else None
-        dx = K.layernorm_bwd(dy.contiguous(), h, stats, gamma.detach(), dgamma=dg, dbeta=db, twin=tw)
+        dx = _ln_bwd(dy.contiguous(), h, stats, gamma.detach(), dgamma=dg, dbeta=db, twin=tw)
         if tw:
             _register_twin(dx, tw[0])
-        _notify(gamma, beta)
+        _tn_notify(gamma, beta)          # (held until the parked dgamma / dbeta partials are summed)
         dxx = dx if ctx.xdtype == F32 else dx.to(ctx.xdtype)
         dr = None
         if ctx.has_res:
@@ -817,7 +859,7 @@ class SwinBlockFn(torch.autograd.Function):
         if train:
             _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
         tw = []
-        dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
+        dx1 = _ln_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
         # attention branch
         dx1h = tw[0]
@@ -827,14 +869,14 @@ class SwinBlockFn(torch.autograd.Function):
         if train:
             _branch_wgrad(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj), s1)
         # (the kernels add the relative-position-table gradient and the padding-slot share of the qkv-bias gradient straight into .grad)
-        dqkv = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn, dattn.view(B, H, W, C), ws, shift, scale,
+        dqkv = _wattn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn, dattn.view(B, H, W, C), ws, shift, scale,
                                  dtable=grad_buf(table) if train else None, dbias=grad_buf(bqkv) if train else None)
         dqkv2 = dqkv.view(M, 3 * C)
         dxn = K.gemm_nt(dqkv2, CACHE.mat_t(wqkv))
         if train:
             _tn(dqkv2, xn, grad_buf(wqkv), grad_buf(bqkv), (wqkv, bqkv))
         tw = []
-        dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
+        dx = _ln_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
                              dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None, twin=tw)
         _register_twin(dx, tw[0])                           # the previous block's backward starts from dx in bf16
         if train:
@@ -930,7 +972,7 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         gb = (lambda p: grad_buf(p)) if train else (lambda p: None)
         # FFN block
         tw = []
-        dh2 = K.layernorm_bwd(dy, h2, st2, g2.detach(), dgamma=gb(g2), dbeta=gb(b2), twin=tw)       # also the skip-path gradient of s1
+        dh2 = _ln_bwd(dy, h2, st2, g2.detach(), dgamma=gb(g2), dbeta=gb(b2), twin=tw)       # also the skip-path gradient of s1
         dh2_16 = tw[0]
         drop = ctx.drop
         inv_keep = 1.0
@@ -944,7 +986,7 @@ class DeformEncoderLayerFn(torch.autograd.Function):
             _tn(df, s1_16, grad_buf(w1), grad_buf(bb1), (w1, bb1))
         # attention block
         tw = []
-        dh1 = K.layernorm_bwd(ds1, h1, st1, g1.detach(), dgamma=gb(g1), dbeta=gb(b1), twin=tw)      # also the skip-path gradient of src
+        dh1 = _ln_bwd(ds1, h1, st1, g1.detach(), dgamma=gb(g1), dbeta=gb(b1), twin=tw)      # also the skip-path gradient of src
         dh1_16 = tw[0]
         if drop is not None:
             K.dropout_bf16(dh1_16, drop[1], drop[0], out=dh1_16)
@@ -1307,7 +1349,7 @@ class NATLayerFn(torch.autograd.Function):
         if train:
             _tn(dh, xn2, grad_buf(w1), grad_buf(bb1), (w1, bb1))
         tw = []
-        dx1 = K.layernorm_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
+        dx1 = _ln_bwd(dxn2, x1, st2, g2.detach(), dres=d2,
                               dgamma=grad_buf(g2) if train else None, dbeta=grad_buf(b2) if train else None, twin=tw)
         dx1h = tw[0]
         if K.EXACT:
@@ -1322,7 +1364,7 @@ class NATLayerFn(torch.autograd.Function):
         if train:
             _tn(dqkv2, xn, grad_buf(wqkv), None if bqkv is None else grad_buf(bqkv), (wqkv, bqkv))
         tw = []
-        dx = K.layernorm_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
+        dx = _ln_bwd(dxn, x2, st1, g1.detach(), dres=dx1,
                              dgamma=grad_buf(g1) if train else None, dbeta=grad_buf(b1) if train else None, twin=tw)
         _register_twin(dx, tw[0])
         if train:
@@ -1426,10 +1468,10 @@ class PatchMergeLnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats, gamma, beta = ctx.saved_tensors
         train = gamma.requires_grad
-        dx = K.patch_merge_ln_bwd(dy if dy.is_contiguous() else dy.contiguous(), x, stats, gamma.detach(),
+        dx = _pm_ln_bwd(dy if dy.is_contiguous() else dy.contiguous(), x, stats, gamma.detach(),
                                   grad_buf(gamma) if train else None, grad_buf(beta) if train else None)
         if train:
-            _notify(gamma, beta)
+            _tn_notify(gamma, beta)          # (held until the parked dgamma / dbeta partials are summed)
         return dx, None, None, None
 
 
