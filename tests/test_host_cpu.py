@@ -143,3 +143,26 @@ def test_mask_bounding_boxes_match_the_per_mask_loop():
     assert torch.equal(got, want) and got.dtype == torch.float32
     assert tuple(got[3].tolist()) == (9.0, 5.0, 10.0, 6.0) and tuple(got[4].tolist()) == (0.0, 0.0, 17.0, 13.0)
     assert mask_bounding_boxes(torch.zeros(0, 4, 4, dtype=torch.bool)).shape == (0, 4)
+
+
+def test_small_reductions_arena_and_descriptors():
+    """uenc.kernels.SmallReductions (the queue of deferred LayerNorm / position-table reductions): buffers are bump-allocated from chunks
+    that persist across flushes, stay disjoint until the flush, and the descriptor records match the 40-byte C structs."""
+    import numpy as np
+    import torch
+    from uenc import kernels as K
+    q = K.SmallReductions()
+    dev = torch.device("cpu")
+    a, b = q.alloc(1000, dev), q.alloc(3000, dev)
+    assert a.dtype == torch.float32 and a.numel() == 1000 and b.numel() == 3000
+    assert b.data_ptr() >= a.data_ptr() + 4000 and (b.data_ptr() - a.data_ptr()) % 256 == 0          # disjoint, 256-byte granules
+    big = q.alloc(q.CHUNK // 4 + 10, dev)                                                             # larger than a chunk: its own chunk
+    assert big.numel() == q.CHUNK // 4 + 10 and len(q._chunks) == 2
+    q.add_ln(a, torch.zeros(8), torch.zeros(8), 4, 8)
+    assert bool(q) and len(q.keep) == 1
+    q.clear()
+    assert not q and q.alloc(10, dev).data_ptr() == a.data_ptr() and len(q._chunks) == 2              # the arena is reused, not re-allocated
+    assert np.dtype(K.SmallReductions._LN).itemsize == 40 and np.dtype(K.SmallReductions._DT).itemsize == 40
+    # the library's own rule for when a LayerNorm backward stores block partials (few rows: it adds its sums itself, nothing to defer)
+    assert K.lib.uenc_layernorm_bwd_blocks(16384, 768) == 2048 and K.lib.uenc_layernorm_bwd_blocks(300, 256) == 0
+    assert K.lib.uenc_window_attn_bwd_groups(2, 64, 128, 24, 12) == 10
