@@ -1,10 +1,11 @@
 """Per-kernel and per-phase breakdown of the last full bench step in a rocprofv3 --kernel-trace CSV.
 usage: python tools/step_breakdown.py gpurun_out/<dir>/p_kernel_trace.csv [top]
 Steps are delimited by the one-per-step cast_multi_kernel launch; phases by the first launch of a phase's signature kernel."""
-import collections, csv, re, sys
+import collections, csv, os, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-st = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')[:64]) for r in rows)
+NAMEW = int(os.environ.get("NAME_WIDTH", "64"))
+st = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')[:NAMEW]) for r in rows)
 idx = [i for i, r in enumerate(st) if 'cast_multi' in r[2]]
 seg = st[idx[-2]:idx[-1]]
 t0 = seg[0][0]
@@ -32,6 +33,15 @@ if os.environ.get("PHASE_DETAIL"):
         print(f"---- {name}")
         for n, t in pt.most_common(int(os.environ["PHASE_DETAIL"])):
             print(f"   {t / 1e6:8.3f} {pc[n]:5d}  {n}")
+if os.environ.get("PHASE_SEQ"):        # the ordered launch sequence of the phases whose name contains the string: offset, duration, idle gap before it
+    for (name, lo), (_, hi) in zip(marks, marks[1:]):
+        if os.environ["PHASE_SEQ"] not in name: continue
+        print(f"==== sequence of {name}")
+        prev = None
+        for s, e, n in seg:
+            if lo <= (s - t0) / 1e6 < hi:
+                print(f"  {(s - t0) / 1e3:10.1f} us  {(e - s) / 1e3:8.1f}  gap {((s - prev) / 1e3 if prev else 0):7.1f}  {n}")
+                prev = e
 tot, cnt = collections.Counter(), collections.Counter()
 for s, e, n in seg:
     tot[n] += e - s; cnt[n] += 1

@@ -1135,7 +1135,14 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
                      ((p.atomic || partials) ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
-    const bool half_tile = big && !p.atomic && !partials && (K % BK3 == 0) && nt128_wins(M, N, K, epilogue, c_dtype, p.variant);
+    // too few 256 x 256 tiles for the one-workgroup-per-CU kernel, but >= 96 tiles of 128 x 256 (stage 4 of Swin-L: M = 4096, N = 1536: 192; the
+    // key / value projections of the decoder's smaller pyramid levels): the half-height kernel instead of the register-staged 128 x 128 one
+    // (bit 2097152 of UENC_GEMM_VARIANT: the old choice, A/B)
+    const long htiles = (long)((M + 127) / 128) * ((N + 255) / 256);
+    const bool mid = !big && batch == 1 && a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
+                     !p.atomic && !partials && htiles >= 96 && !(p.variant & 2097152) &&
+                     (c_dtype == UENC_F32 ? (epilogue == EPI_NONE || epilogue == EPI_RESIDUAL || epilogue == EPI_RELU) : true);
+    const bool half_tile = mid || (big && !p.atomic && !partials && (K % BK3 == 0) && nt128_wins(M, N, K, epilogue, c_dtype, p.variant));
     if (prof) {
         // algorithmic HBM bytes: A, W and the output once, plus what the epilogue reads (residual / saved activation) or writes besides
         const double mn = (double)M * N;
@@ -1177,7 +1184,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         if (prof) uenc_prof_end(stream);
         UENC_LAUNCH_RET();
     }
-    if (big) {
+    if (big || mid) {
         int rc = UENC_EINVAL;
 #define LAUNCH2(E, F) rc = half_tile ? launch_nt128<E, F>(p, stream) : (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
         if (c_dtype == UENC_F32) {
