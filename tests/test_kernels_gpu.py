@@ -314,6 +314,50 @@ def test_gemm_nt_large_tile_path(K, M, N, K_):
     _close(K.gemm_nt(ai, wi, out_dtype=torch.float32), ai.float() @ wi.float().t(), 0, 0)
 
 
+@pytest.mark.parametrize("M,N,K_", [(40008, 520, 128), (41000, 776, 320), (45000, 200, 192), (16384, 768, 768), (66000, 384, 64 * 7)])
+def test_gemm_nt_192_wide_tile(K, M, N, K_, monkeypatch):
+    """The 256 x 192 tile of the persistent LDS-DMA kernel (three 16-MFMA phases per k-tile, an unpaired third column group per wave) forced on
+    ragged shapes -- last column tile 136 / 8 / 192 wide, 2 ... 12 k-tiles, persistent and one-tile-per-workgroup grids -- against the
+    256-wide tile (bit-identical: same k order) and against fp32 matmul, every epilogue."""
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias = _r(N, seed=3)
+    res = _r(M, N, seed=4)
+    saved = _r(M, N, seed=5, dtype=torch.bfloat16)
+    pre = a.float() @ w.float().t() + bias
+
+    def run_all():
+        outs = [K.gemm_nt(a, w, bias=bias, out_dtype=torch.float32), K.gemm_nt(a, w, bias=bias)]
+        po = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        outs += [K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_GELU, aux_out=po), po]
+        outs.append(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RELU))
+        outs.append(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=torch.float32))
+        outs.append(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=torch.bfloat16))
+        outs.append(K.gemm_nt(a, w, epilogue=K.EPI_MUL_DGELU, aux=saved))
+        outs.append(K.gemm_nt(a, w, epilogue=K.EPI_MUL_DRELU, aux=saved))
+        outs.append(K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RELU, out_dtype=torch.float32))
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv("UENC_GEMM_VARIANT", str(262144 | 8388608))
+    wide = run_all()
+    monkeypatch.setenv("UENC_GEMM_VARIANT", str(262144 | 4194304))
+    narrow = run_all()
+    for x, y in zip(wide, narrow):
+        assert torch.equal(x, y)
+    _close(narrow[0], pre, 2e-3, 2e-3)
+    _close(narrow[1], pre, 2e-2, 1e-2)
+    _close(narrow[2], torch.nn.functional.gelu(pre), 2e-2, 1e-2)
+    _close(narrow[3], pre, 2e-2, 1e-2)
+    _close(narrow[5], pre + res, 2e-3, 2e-3)
+    _close(narrow[6], pre + res, 3e-2, 1e-2)
+    _close(narrow[8], (pre - bias) * (saved.float() > 0), 3e-2, 2e-2)
+    ai = (torch.arange(M * K_, dtype=torch.float32).reshape(M, K_) % 7 - 3).to(torch.bfloat16).cuda()
+    wi = (torch.arange(N * K_, dtype=torch.float32).reshape(N, K_) % 5 - 2).to(torch.bfloat16).cuda()
+    _close(K.gemm_nt(ai, wi, out_dtype=torch.float32), ai.float() @ wi.float().t(), 0, 0)
+    _close(K.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(torch.bfloat16).float(), 0, 0)
+
+
 @pytest.mark.parametrize("M,N,K_,split", [(150, 256, 32768, 64), (600, 512, 8192, 16), (1000, 256, 4096 + 64, 16)])
 def test_gemm_nt_splitk_large_tile(K, M, N, K_, split):
     """Split-K on the 256x256 LDS-DMA kernel (skinny outputs with a long contraction: the mask-embedding gradient)."""

@@ -411,12 +411,16 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNT p) {
 #define BN2 256
 #define T2 512
 
-// counted wait on the VM counter (LDS-DMA and global loads / stores in flight): n in {0, 2, 4, 6, 8}
+// counted wait on the VM counter (LDS-DMA and global loads / stores in flight): at most n (0 .. 8) of this wave's operations stay in flight
 __device__ __forceinline__ void wait_vmcnt_upto8(int n) {
     if (n >= 8) __builtin_amdgcn_s_waitcnt(0x0f78);
+    else if (n == 7) __builtin_amdgcn_s_waitcnt(0x0f77);
     else if (n == 6) __builtin_amdgcn_s_waitcnt(0x0f76);
+    else if (n == 5) __builtin_amdgcn_s_waitcnt(0x0f75);
     else if (n == 4) __builtin_amdgcn_s_waitcnt(0x0f74);
+    else if (n == 3) __builtin_amdgcn_s_waitcnt(0x0f73);
     else if (n == 2) __builtin_amdgcn_s_waitcnt(0x0f72);
+    else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0f71);
     else __builtin_amdgcn_s_waitcnt(0x0f70);
 }
 
@@ -431,12 +435,18 @@ __device__ __forceinline__ void wait_vmcnt_upto8(int n) {
 // direct form is 5-13 % faster per launch for bf16 results.  fp32 results keep the staged form: its 1 KB runs per row beat
 // 64-byte (direct) and 256-byte (per-wave patches) runs by 7-20 % on the HBM-bound shapes.  Bit 32768 of UENC_GEMM_VARIANT
 // selects the staged form everywhere (A/B).
-template <int EPI>
+// NI = column groups of 16 the wave owns (4: the 64-wide patch; 3: the 48-wide patch of the 256 x 192 tile -- its third group has no
+// partner to trade halves with and moves as 8-byte pieces: a third of the tile's bytes in 32-byte runs).
+template <int EPI, int NI = 4>
 __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)[4][8], int mbase, int nbase, int fr, int fg, bool lead) {
+    static_assert(NI == 4 || NI == 3, "column groups per wave");
+    constexpr int NP = NI / 2;                          // pairs of column groups stored as 16-byte pieces
+    constexpr bool ODD = (NI & 1) != 0;
     const int mrow = mbase + fr, ncol = nbase + 4 * fg;
+    const int nodd = ncol + (NI - 1) * 16;              // this lane's 4 columns of the unpaired group
     float bv4[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int n = ncol + i * 16;
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias != nullptr && n < p.N && lead) b = *(const float4*)(p.bias + n);
@@ -453,6 +463,7 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
     constexpr bool AUX16 = (EPI == EPI_MUL_DGELU || EPI == EPI_MUL_DRELU);
     const bool hoist = !(p.variant & 1048576);
     u32x4 xa[AUX16 ? 4 : 1][2];                         // saved bf16 activation: four rows at a time (32 registers)
+    u32x2 xo[AUX16 && ODD ? 4 : 1];                     // ... of the unpaired group
     float4 ra[EPI == EPI_RESIDUAL ? 2 : 1][4];          // fp32 residual: two rows at a time (32 registers)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -460,19 +471,24 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
         const bool row_ok = m < p.M;
         if (AUX16 && hoist && (j & 3) == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj) {
+                const int mm = mrow + (j + jj) * 16;
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int mm = mrow + (j + jj) * 16;
+                for (int pr = 0; pr < NP; ++pr) {
                     xa[jj][pr] = (u32x4){0u, 0u, 0u, 0u};
                     if (mm < p.M && n16[pr] < p.N) xa[jj][pr] = *(const u32x4*)((const bf16*)p.aux + (long)mm * p.ldaux + n16[pr]);
                 }
+                if (ODD) {
+                    xo[AUX16 && ODD ? jj : 0] = (u32x2){0u, 0u};
+                    if (mm < p.M && nodd < p.N) xo[AUX16 && ODD ? jj : 0] = *(const u32x2*)((const bf16*)p.aux + (long)mm * p.ldaux + nodd);
+                }
+            }
         }
         if (EPI == EPI_RESIDUAL && hoist && (j & 1) == 0) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const int mm = mrow + (j + jj) * 16, n = ncol + i * 16;
                     ra[jj][i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (mm < p.M && n < p.N) ra[jj][i] = *(const float4*)((const float*)p.aux + (long)mm * p.ldaux + n);
@@ -481,13 +497,13 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
         float v[4][4];
         const float al = nt_alpha(p, min(m, p.M - 1));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i][r] = (acc[i][j][r] + bv4[i][r]) * al;
         u32x2 pre2[4];
         if (EPI == EPI_GELU) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 bf16x4 q;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { q[r] = (bf16)v[i][r]; v[i][r] = gelu_f(v[i][r]); }
@@ -495,12 +511,12 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
             }
         } else if (EPI == EPI_RELU) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(v[i][r], 0.f);
         } else if (EPI == EPI_RESIDUAL) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int n = ncol + i * 16;
                 if (hoist) {
                     const float4 r0 = ra[j & 1][i];
@@ -514,7 +530,7 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
             // the saved bf16 activation is read in the widened layout (16 bytes per lane) and brought back to the accumulator
             // layout by the same swap (an involution)
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
+            for (int pr = 0; pr < NP; ++pr) {
                 u32x4 x = {0u, 0u, 0u, 0u};
                 if (hoist) x = xa[AUX16 ? (j & 3) : 0][pr];
                 else if (row_ok && n16[pr] < p.N) x = *(const u32x4*)((const bf16*)p.aux + (long)m * p.ldaux + n16[pr]);
@@ -528,18 +544,28 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
                     v[2 * pr + 1][r] = (EPI == EPI_MUL_DGELU) ? v[2 * pr + 1][r] * dgelu_f((float)s1[r]) : (((float)s1[r] > 0.f) ? v[2 * pr + 1][r] : 0.f);
                 }
             }
+            if (ODD) {                                  // the unpaired group: already in the accumulator layout
+                u32x2 x = {0u, 0u};
+                if (hoist) x = xo[AUX16 && ODD ? (j & 3) : 0];
+                else if (row_ok && nodd < p.N) x = *(const u32x2*)((const bf16*)p.aux + (long)m * p.ldaux + nodd);
+                const bf16x4 s0 = *(const bf16x4*)&x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[NI - 1][r] = (EPI == EPI_MUL_DGELU) ? v[NI - 1][r] * dgelu_f((float)s0[r]) : (((float)s0[r] > 0.f) ? v[NI - 1][r] : 0.f);
+            }
         }
         {
             u32x2 o2[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 bf16x4 q;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) q[r] = (bf16)v[i][r];
                 o2[i] = *(const u32x2*)&q;
             }
+            if (ODD && row_ok && nodd < p.N) *(u32x2*)((bf16*)p.C + (long)m * p.ldc + nodd) = o2[NI - 1];
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
+            for (int pr = 0; pr < NP; ++pr) {
                 const u32x2 lo = __builtin_amdgcn_permlane16_swap(o2[2 * pr][0], o2[2 * pr + 1][0], false, false);
                 const u32x2 hi = __builtin_amdgcn_permlane16_swap(o2[2 * pr][1], o2[2 * pr + 1][1], false, false);
                 if (row_ok && n16[pr] < p.N) {
@@ -550,8 +576,9 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
             }
         }
         if (EPI == EPI_GELU && p.aux_out != nullptr) {
+            if (ODD && row_ok && nodd < p.N) *(u32x2*)(p.aux_out + (long)m * p.ldaux_out + nodd) = pre2[NI - 1];
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
+            for (int pr = 0; pr < NP; ++pr) {
                 const u32x2 lo = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][0], pre2[2 * pr + 1][0], false, false);
                 const u32x2 hi = __builtin_amdgcn_permlane16_swap(pre2[2 * pr][1], pre2[2 * pr + 1][1], false, false);
                 if (row_ok && n16[pr] < p.N) {
@@ -566,7 +593,8 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
 
 // ---- LDS-staged epilogue (fp32 results; bf16 under UENC_GEMM_VARIANT bit 32768): passes of 64 rows through a padded fp32 tile [64][260]
 // in LDS, then 8 consecutive columns per thread: 1 KB runs per row.  NWM = row groups of 128 the workgroup owns (wave group wm each). ----
-template <int EPI, int OUT_F32, int NTHREADS, int NWM>
+// NI = column groups of 16 per wave (4, or 3 for the 192-wide tile: the tile then spans 4 x 48 columns and the threads of the last 64 idle).
+template <int EPI, int OUT_F32, int NTHREADS, int NWM, int NI = 4>
 __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)[4][8], unsigned char* smem, int m0, int n0, int wm, int wn,
                                                    int t, int fr, int fg, bool lead, bool skip_stores) {
     float* T = (float*)smem;
@@ -576,7 +604,7 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
     constexpr int NIT = 64 / RPI;
     const bool hoist = !(p.variant & 1048576);
     const int n = n0 + ecol;
-    const bool ncol_ok = n < p.N;
+    const bool ncol_ok = n < p.N && ecol < NI * 64;
     const bool full8 = (n + 8 <= p.N);
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr && ncol_ok && lead) {
@@ -610,7 +638,7 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = (ps & 1) * 4 + jj;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *(f32x4*)(T + (jj * 16 + fr) * LDT + wn * 64 + i * 16 + 4 * fg) = acc[i][j];
+                for (int i = 0; i < NI; ++i) *(f32x4*)(T + (jj * 16 + fr) * LDT + wn * (NI * 16) + i * 16 + 4 * fg) = acc[i][j];
             }
         }
         __syncthreads();
@@ -695,8 +723,16 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
     }
 }
 
-template <int EPI, int OUT_F32, int PIPE>
+// BNT = 192: the 256 x 192 tile (PIPE = 1 only).  A wave then owns 128 x 48 = three column groups: B0 keeps the first two, B1 is the third
+// alone (a 64-row, 8 KB half-tile: ONE DMA instruction per thread, and quadrants of 16 / 8 / 8 / 16 MFMAs).  For the shapes whose
+// 256-wide tiling leaves CUs idle or columns empty: N = 768 at M = 16384 is 192 tiles of 256 x 256 on 256 CUs but 256 tiles of
+// 256 x 192; N = 2304 is 2.25 rounds of tiles against 3 rounds of 3/4 the work; N = 384 / 576 / 192 waste a quarter of their last column.
+template <int EPI, int OUT_F32, int PIPE, int BNT = BN2>
 __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
+    static_assert(BNT == 256 || (BNT == 192 && PIPE == 1), "tile width");
+    constexpr int NI = BNT / 64;          // column groups of 16 per wave
+    constexpr int NB1 = NI - 2;           // ... of them in the B1 half-tile
+    constexpr int BNW = BNT / 4;          // columns per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 stages x (A 32 KB + W 32 KB)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -712,7 +748,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     for (;;) {
     const int tile = xcd_remap(pos, ntiles_all);
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
-    const int m0 = mt * BM2, n0 = nt * BN2;
+    const int m0 = mt * BM2, n0 = nt * BNT;
     const int pos_next = pos + (int)gridDim.x;
     const bool has_next = p.persist && pos_next < ntiles_all;
     // split-K (EPI_NONE, fp32 C, pre-zeroed or accumulated into): blockIdx.y owns k-tiles [kt0, kt0 + nkt), adds its tile atomically
@@ -744,11 +780,12 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             for (int q = 0; q < 2; ++q) {
                 const int lr = q * 64 + (t >> 3), slot = t & 7;
                 const int chunk = slot ^ ((lr >> 1) & 7);
-                const int ra = (lr >> 6) * 128 + (lr & 63), rb = (lr >> 5) * 64 + (lr & 31);
+                const int ra = (lr >> 6) * 128 + (lr & 63), rb = (lr >> 5) * BNW + (lr & 31);
+                const int rb1 = NB1 == 2 ? rb + 32 : (lr >> 4) * BNW + 32 + (lr & 15);      // (192: B1 has 64 rows, 16 per wave; only q = 0 is issued)
                 src[0][q] = (const bf16*)p.A + (long)min(mm0 + ra, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
                 src[3][q] = (const bf16*)p.A + (long)min(mm0 + ra + 64, p.M - 1) * p.lda + chunk * 8 + (long)kt0 * BK;
                 src[1][q] = p.W + (long)min(nn0 + rb, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
-                src[2][q] = p.W + (long)min(nn0 + rb + 32, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
+                src[2][q] = p.W + (long)min(nn0 + rb1, p.N - 1) * p.ldw + chunk * 8 + (long)kt0 * BK;
             }
         };
         if (!prefetched) set_src(m0, n0);
@@ -758,22 +795,119 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             unsigned char* dst = smem + (tile & 1) * 65536 + (o == 0 ? 0 : o == 1 ? 32768 : o == 2 ? 49152 : 16384) + wave * 1024;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                __builtin_amdgcn_global_load_lds(src[o][q] + (long)tile * BK, (lds_void*)(dst + q * 8192), 16, 0, 0);
+                if (q == 0 || o != 2 || NB1 == 2)
+                    __builtin_amdgcn_global_load_lds(src[o][q] + (long)tile * BK, (lds_void*)(dst + q * 8192), 16, 0, 0);
+        };
+        // DMA instructions of this thread still in flight when half-tiles first .. min(first + 3, U - 1) are (2 each; 1 for the 64-row B1)
+        auto inflight = [&](int first) {
+            if (NB1 == 2) return 2 * min(max(U - first, 0), 4);
+            int n = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (first + k < U) n += (((first + k) & 3) == 2) ? 1 : 2;
+            return n;
         };
         // prologue: half-tiles 0..5 (k-tile 0 and A0, B0 of k-tile 1); A0, B0 of k-tile 0 must have landed everywhere before phase 0
+        // (the 192-wide tile consumes a k-tile as A0 B0 | A1 | B1 and issues in that order: see its loop below)
         auto prologue = [&]() {
-            issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+            if (BNT == 192) { issue(0, 0); issue(1, 0); issue(3, 0); issue(2, 0); }
+            else { issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); }
             if (U > 4) { issue(0, 1); issue(1, 1); }
         };
         if (!prefetched) prologue();
         // (a prefetched prologue is followed by the previous tile's result stores: they are younger, so this wait also covers them
         // up to the last 8 -- conservative, never early)
-        wait_vmcnt_upto8(U > 4 ? 8 : 4);
+        if (BNT == 192) wait_vmcnt_upto8(3 + (U > 4 ? 4 : 0));  // (A1, B1 of k-tile 0 and A0, B0 of k-tile 1 may still be in flight)
+        else wait_vmcnt_upto8(inflight(2));                    // (half-tiles 2 .. 5 may still be in flight)
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();             // the stagger: group 1 runs one barrier behind group 0
 
         const int aoff = lds_off(wm * 64 + fr, fg), boff = lds_off(wn * 32 + fr, fg);      // row + 16 j keeps (row >> 1) & 7 -> + 2048 j
-        bf16x8 af[4][2], b0[2][2], b1[2][2];
+        const int boff1 = NB1 == 2 ? boff : lds_off(wn * 16 + fr, fg);
+        if constexpr (BNT == 192) {
+        // ---- 256 x 192: THREE phases of 16 MFMAs per k-tile (the four-quadrant order would give 16 / 8 / 8 / 16, and an 8-MFMA phase
+        // is shorter than the other wave group's LDS reads it has to cover: measured 35-43 % slower per flop than the 256-wide tile) ----
+        //     a: read B0 (2 column groups), A0 | issue A1 of k-tile T+1       | (A0, B0): 16 MFMAs
+        //     b: read A1                        | issue B1 of k-tile T+1       | (A1, B0): 16 MFMAs
+        //     c: read B1 (1 column group)       | issue A0, B0 of k-tile T+2   | (A0 and A1, B1): 16 MFMAs   (A0 stays in registers)
+        // Every DMA goes into a slot last read two phases before (the other wave group runs one barrier behind and may still have that
+        // slot's ds_reads in flight one phase after); the stream order per k-tile is A0 B0 A1 B1 = the order of use, each piece one
+        // k-tile (three phases) ahead of its reads.  The wait of a phase covers the NEXT phase's operands in this wave; the barrier
+        // pair that follows covers the other waves'.  After the required piece at most 7 instructions are younger (2 + 2 + 2 + 1).
+        bf16x8 af0[4][2], af1[4][2], b0[2][2], b1[1][2];
+        for (int T = 0; T < nkt; ++T) {
+            const unsigned char* buf = smem + (T & 1) * 65536;
+            const bool n1 = T + 1 < nkt, n2 = T + 2 < nkt;
+            // phase a
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b0[i][ks] = *(const bf16x8*)(buf + 32768 + i * 2048 + (boff ^ (ks << 6)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af0[j][ks] = *(const bf16x8*)(buf + j * 2048 + (aoff ^ (ks << 6)));
+            if (n1) issue(3, T + 1);
+            wait_vmcnt_upto8(n1 ? 7 : 1);                      // A1 of this k-tile has landed (B1 and the next k-tile may be in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b0[i][ks], af0[j][ks], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // phase b
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af1[j][ks] = *(const bf16x8*)(buf + 16384 + j * 2048 + (aoff ^ (ks << 6)));
+            if (n1) issue(2, T + 1);
+            wait_vmcnt_upto8(n1 ? 7 : 0);                      // B1 of this k-tile has landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][4 + j] = mfma16(b0[i][ks], af1[j][ks], acc[i][4 + j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // phase c
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b1[0][ks] = *(const bf16x8*)(buf + 49152 + (boff1 ^ (ks << 6)));
+            if (n2) { issue(0, T + 2); issue(1, T + 2); }
+            wait_vmcnt_upto8((n1 ? 3 : 0) + (n2 ? 4 : 0));     // A0, B0 of the next k-tile have landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[2][j] = mfma16(b1[0][ks], af0[j][ks], acc[2][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[2][4 + j] = mfma16(b1[0][ks], af1[j][ks], acc[2][4 + j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        } else {
+        bf16x8 af[4][2], b0[2][2], b1[NB1][2];
         for (int T = 0; T < nkt; ++T) {
             const unsigned char* buf = smem + (T & 1) * 65536;
             const int s = 4 * T;
@@ -788,7 +922,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) af[j][ks] = *(const bf16x8*)(buf + j * 2048 + (aoff ^ (ks << 6)));
             if (s + 6 < U) issue(2, T + 1);
-            wait_vmcnt_upto8(2 * min(max(U - s - 3, 0), 4));
+            wait_vmcnt_upto8(inflight(s + 3));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -805,11 +939,11 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: B1 -> quadrant (0, 1)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NB1; ++i)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) b1[i][ks] = *(const bf16x8*)(buf + 49152 + i * 2048 + (boff ^ (ks << 6)));
+                for (int ks = 0; ks < 2; ++ks) b1[i][ks] = *(const bf16x8*)(buf + 49152 + i * 2048 + (boff1 ^ (ks << 6)));
             if (s + 7 < U) issue(3, T + 1);
-            wait_vmcnt_upto8(2 * min(max(U - s - 4, 0), 4));
+            wait_vmcnt_upto8(inflight(s + 4));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -817,7 +951,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NB1; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[2 + i][j] = mfma16(b1[i][ks], af[j][ks], acc[2 + i][j]);
             __builtin_amdgcn_s_setprio(0);
@@ -830,7 +964,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) af[j][ks] = *(const bf16x8*)(buf + 16384 + j * 2048 + (aoff ^ (ks << 6)));
             if (s + 8 < U) issue(0, T + 2);
-            wait_vmcnt_upto8(2 * min(max(U - s - 5, 0), 4));
+            wait_vmcnt_upto8(inflight(s + 5));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -838,7 +972,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NB1; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[2 + i][4 + j] = mfma16(b1[i][ks], af[j][ks], acc[2 + i][4 + j]);
             __builtin_amdgcn_s_setprio(0);
@@ -847,7 +981,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             __builtin_amdgcn_sched_barrier(0);
             // phase 4: (B0 still in registers) -> quadrant (1, 0)
             if (s + 9 < U) issue(1, T + 2);
-            wait_vmcnt_upto8(2 * min(max(U - s - 6, 0), 4));
+            wait_vmcnt_upto8(inflight(s + 6));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -863,12 +997,13 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         if (wm == 0) __builtin_amdgcn_s_barrier();             // group 0 waits for group 1's last phase
         prefetched = false;
         if (has_next && !OUT_F32 && !(p.variant & 32768)) {     // the register-direct epilogue does not touch LDS: start the next tile's loads now
             const int tile2 = xcd_remap(pos_next, ntiles_all);
             const int mt2 = tile2 / p.tiles_n;
-            set_src(mt2 * BM2, (tile2 - mt2 * p.tiles_n) * BN2);
+            set_src(mt2 * BM2, (tile2 - mt2 * p.tiles_n) * BNT);
             __builtin_amdgcn_sched_barrier(0);
             prologue();
             prefetched = true;
@@ -927,12 +1062,12 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
         continue;
     }
     if (!OUT_F32 && !(p.variant & 32768)) {
-        nt_epilogue_direct<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, fr, fg, blockIdx.y == 0);
+        nt_epilogue_direct<EPI, NI>(p, acc, m0 + wm * 128, n0 + wn * BNW, fr, fg, blockIdx.y == 0);
         if (!has_next) return;
         pos = pos_next;
         continue;
     }
-    nt_epilogue_staged<EPI, OUT_F32, T2, 2>(p, acc, smem, m0, n0, wm, wn, t, fr, fg, blockIdx.y == 0, (p.variant & 8192) != 0);
+    nt_epilogue_staged<EPI, OUT_F32, T2, 2, NI>(p, acc, smem, m0, n0, wm, wn, t, fr, fg, blockIdx.y == 0, (p.variant & 8192) != 0);
     if (!has_next) return;
     __syncthreads();          // the staged epilogue's last reads of the LDS tile precede the next tile's DMA writes
     pos = pos_next;
@@ -1049,26 +1184,44 @@ static int launch_nt128(GemmNT& p, hipStream_t stream) {
     return UENC_OK;
 }
 
-template <int EPI, int OUT_F32, int PIPE>
-static int launch_nt256(GemmNT& p, hipStream_t stream) {
-    p.tiles_m = (p.M + BM2 - 1) / BM2; p.tiles_n = (p.N + BN2 - 1) / BN2;
-    static bool attr_set = false;      // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    // more tiles than CUs: one persistent workgroup per CU walks its tile positions (bit 65536 of UENC_GEMM_VARIANT: one workgroup per tile)
+static int nt_cu_count() {
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) ncu = v / 8 * 8;
         else ncu = 256;
     }
+    return ncu;
+}
+
+template <int EPI, int OUT_F32, int PIPE, int BNT = BN2>
+static int launch_nt256(GemmNT& p, hipStream_t stream) {
+    p.tiles_m = (p.M + BM2 - 1) / BM2; p.tiles_n = (p.N + BNT - 1) / BNT;
+    static bool attr_set = false;      // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32, PIPE, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    // more tiles than CUs: one persistent workgroup per CU walks its tile positions (bit 65536 of UENC_GEMM_VARIANT: one workgroup per tile)
+    const int ncu = nt_cu_count();
     const int ntiles = p.tiles_m * p.tiles_n;
     p.persist = (PIPE == 1 && p.splits == 1 && ntiles > ncu && !(p.variant & 65536)) ? 1 : 0;
-    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE>), dim3(p.persist ? ncu : ntiles, p.splits), dim3(T2), 131072, stream, p);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE, BNT>), dim3(p.persist ? ncu : ntiles, p.splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
+}
+
+// 256 x 192 or 256 x 256 tiles?  Rounds of tiles over the CUs x cost per tile.  Measured (tools/gemm_nt192_ab.py ->
+// profiles/r03_gemm_nt192_ab.txt): a 192-wide tile costs 0.85-0.92 of a 256-wide one, not 0.75 (its DMA stream runs one k-tile ahead
+// instead of 1.5, and 22 instead of 24 ds_reads feed 48 instead of 64 MFMAs), so it is taken where it saves a round or a quarter-empty
+// column: N = 768 / 2304 at M = 16384 (-8...-10 %), N = 384 (-8...-12 %), N = 4608 / 6144 at M = 4096 (-5...-15 %); neutral on the HBM-bound
+// N = 192 / 576 launches of stage 1.  UENC_GEMM_VARIANT bit 4194304 forces the 192-wide tile wherever it is legal, bit 8388608 forbids it (A/B).
+static bool nt192_wins(int M, int N, int variant) {
+    if (variant & 8388608) return false;
+    if (variant & 4194304) return true;
+    const long ncu = nt_cu_count(), tm = (M + BM2 - 1) / BM2;
+    const long r256 = (tm * ((N + 255) / 256) + ncu - 1) / ncu, r192 = (tm * ((N + 191) / 192) + ncu - 1) / ncu;
+    return r192 * 90 < r256 * 100;
 }
 
 // Which of the two large-tile kernels takes a shape (both compute the same sums in the same k order: identical results).
@@ -1186,7 +1339,8 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     }
     if (big || mid) {
         int rc = UENC_EINVAL;
-#define LAUNCH2(E, F) rc = half_tile ? launch_nt128<E, F>(p, stream) : (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
+        const bool narrow = big && !half_tile && !p.atomic && !partials && nt192_wins(M, N, p.variant);
+#define LAUNCH2(E, F) rc = half_tile ? launch_nt128<E, F>(p, stream) : (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : narrow ? launch_nt256<E, F, 1, 192>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
         if (c_dtype == UENC_F32) {
             if (epilogue == EPI_NONE) LAUNCH2(EPI_NONE, 1);
             else if (epilogue == EPI_RESIDUAL) LAUNCH2(EPI_RESIDUAL, 1);
