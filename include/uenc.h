@@ -236,6 +236,15 @@ int uenc_window_attn_dtable_grouped(const void* table, int n, int total_blocks, 
 int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
                            const float* loc, const float* attn, void* out, int out_dtype, int B, int S, int M, int D,
                            int L, int Lq, int P, uenc_stream_t stream);
+/* The same forward for the geometry of the deformable ENCODER (ops/modules/ms_deform_attn.py called from
+ * pixel_decoder/msdeformattn.py:115-121: the queries are the pixels of the L maps, Lq == S, level-major), with the value pixels a
+ * neighbourhood of queries samples staged once per workgroup in LDS instead of gathered tap by tap from L2.  Same arguments and
+ * result plus shapes_host, the HOST copy of `shapes`.  Needs D == 32, bf16 value, L <= 4, L * P <= 16, Lq == S == sum(H_l * W_l);
+ * returns -1 (nothing launched) otherwise -- call uenc_msdeform_attn_fwd then.  Any sampling locations are legal: a level whose
+ * sampled box does not fit the LDS budget is gathered from memory as in the general kernel. */
+int uenc_msdeform_attn_fwd_tiled(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
+                                 const float* loc, const float* attn, void* out, int out_dtype, int B, int S, int M, int D,
+                                 int L, int Lq, int P, const int64_t* shapes_host, uenc_stream_t stream);
 /* ms_deform_attn_backward (ms_deform_attn.h:47-66, cuh:306-408): grad_value fp32 accumulated (caller zeroes,
  * as the reference's at::zeros_like), grad_loc / grad_attn overwritten.  shapes_host: optional HOST copy of `shapes`,
  * workspace: optional device scratch of uenc_msdeform_attn_bwd_workspace_bytes() bytes (both may be NULL).  With them

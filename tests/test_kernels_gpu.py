@@ -543,3 +543,37 @@ def test_msdeform_fused_equals_prep_plus_core(K, shapes_l, spread, ref_batch):
     den = float(d0.float().abs().max())
     assert float((d1.float() - d0.float()).abs().max()) <= 2 ** -7 * den                       # one bf16 ulp of the largest entries
     assert float((d1.float() - d0.float()).norm() / d0.float().norm()) < 2e-3
+
+
+@pytest.mark.parametrize("shapes_l,spread,tile", [([(16, 32), (8, 16), (4, 8)], 4.0, None), ([(27, 43), (13, 22), (7, 11)], 6.0, "8,32,78"),
+                                                  ([(27, 43), (13, 22), (7, 11)], 40.0, "8,16,8"), ([(9, 5)], 3.0, "4,4,1"),
+                                                  ([(33, 70), (17, 35), (9, 18), (5, 9)], 5.0, "16,16,40"),
+                                                  ([(4, 8), (8, 16), (16, 32)], 3.0, None), ([(7, 11), (13, 22), (27, 43)], 6.0, "8,16,30")])
+def test_msdeform_fwd_tiled_equals_gather(K, shapes_l, spread, tile, monkeypatch):
+    """uenc_msdeform_attn_fwd_tiled (encoder geometry: queries = the maps' pixels, value boxes staged in LDS) against the general gather
+    kernel on the same inputs, fp32 and bf16 results: offsets of a few pixels (everything staged), far offsets with a tiny LDS budget (levels
+    fall back to the global gather inside the kernel), samples outside the maps, odd map sizes whose levels do not nest, 1 and 4 levels,
+    levels listed fine-to-coarse and coarse-to-fine (the pixel decoder's order: the regions are cut from the finest map wherever it is).
+    The reference's own op is pinned by test_msdeform_golden; this pins the second kernel to the first."""
+    if tile is not None:
+        monkeypatch.setenv("UENC_MSDA_TILE", tile)            # region size on level 0 and LDS budget in KB (read per launch)
+    L, P, M, D, B = len(shapes_l), 4, 8, 32, 2
+    S = sum(h * w for h, w in shapes_l)
+    gen = torch.Generator().manual_seed(11)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1).reshape(-1, 2).flip(-1)
+                     for h, w in shapes_l])                                                     # (S, 2) as (x, y): pixel centres
+    norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32)                     # (L, 2)
+    off = (torch.rand(B, S, M, L, P, 2, generator=gen) * 2 - 1) * spread
+    loc = (ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).contiguous().cuda()
+    aw = torch.softmax(torch.randn(B, S, M, L * P, generator=gen), -1).view(B, S, M, L, P).contiguous().cuda()
+    value = torch.randn(B, S, M, D, generator=gen).to(torch.bfloat16).cuda()
+    shapes = torch.tensor(shapes_l, dtype=torch.int64).cuda()
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    assert K.msdeform_tiled_eligible(value, shapes_l, S, L, P)
+    for odt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 2 ** -8)):
+        want = K.msdeform_attn_fwd(value, shapes, start, loc, aw, out_dtype=odt)                # no shapes_host: the gather kernel
+        got = K.msdeform_attn_fwd(value, shapes, start, loc, aw, out_dtype=odt, shapes_host=shapes_l)
+        den = float(want.float().abs().max())
+        assert float((got.float() - want.float()).abs().max()) <= tol * den, (odt, float((got.float() - want.float()).abs().max()), den)
+    # not the encoder's geometry: the wrapper must keep the gather kernel (fewer queries than pixels)
+    assert not K.msdeform_tiled_eligible(value, shapes_l, S - 1, L, P)

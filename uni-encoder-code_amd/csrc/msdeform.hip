@@ -114,6 +114,271 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaP p) {
     }
 }
 
+// ---- forward, value tiles in LDS (the deformable ENCODER: the queries are the pixels of the L maps themselves) ----------
+// The gather kernel above reads every tap from L2: 4 taps x L*P samples x 64 bytes per (query, head) = 2.1 GB per encoder layer at
+// 1024 x 2048, 284 us.  In the encoder the queries of a neighbourhood sample a neighbourhood: a workgroup takes ONE head and ONE
+// region of the image -- a TY x TX rectangle of the finest level plus the pixels of the other levels that fall into the same fraction of
+// the image -- and
+//   1. finds, per level, the bounding box of the taps its queries really touch (from the sampling locations: nothing is assumed
+//      about the offsets),
+//   2. copies the boxes that fit the LDS budget into LDS (64 bytes per pixel of this head, each read from L2 once per workgroup),
+//   3. gathers from LDS; a level whose box does not fit is gathered from global memory as before (so any input gives the
+//      reference's result; only the speed depends on how far the offsets reach).
+// A thread owns a (query, head) with all 32 channels.  LDS pixel images are 64 bytes; chunk c of pixel i sits at slot
+// c ^ ((i >> 2) & 3), so that 16 lanes reading the same chunk of 16 neighbouring pixels cover all 64 banks.
+#define MSDT_L 4
+struct MsdaTile {
+    int H[MSDT_L], W[MSDT_L], start[MSDT_L];
+    int RH, RW;                 // the map the regions are cut from: the FINEST level (the pixel decoder lists its levels coarse to fine)
+    int TY, TX, ntx, nregions;  // region size on that map, regions per row / per image
+    int lds_bytes;              // budget for the value tiles
+    int variant;                // timing experiments (UENC_MSDA_VARIANT): 1 = no staging, 2 = stop after staging; 0 in production
+};
+
+__device__ __forceinline__ void msdt_fma8(const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& d, float w1, float w2, float w3, float w4, float* acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[2 * i] += w1 * __uint_as_float(a[i] << 16) + w2 * __uint_as_float(b[i] << 16) + w3 * __uint_as_float(c[i] << 16) + w4 * __uint_as_float(d[i] << 16);
+        acc[2 * i + 1] += w1 * __uint_as_float(a[i] & 0xffff0000u) + w2 * __uint_as_float(b[i] & 0xffff0000u) + w3 * __uint_as_float(c[i] & 0xffff0000u) +
+                          w4 * __uint_as_float(d[i] & 0xffff0000u);
+    }
+}
+
+// P4: P == 4 -- a level's four locations / weights are three 16-byte loads, and all levels' loads are requested before the first sample is
+// used (with a run-time P every sample's location was a dependent global load in front of its LDS reads: 12 exposed L2 round trips per
+// query, and the kernel ran 1.5 x SLOWER than the gather kernel it replaces).
+template <bool P4>
+__global__ __launch_bounds__(384, 3) void msda_fwd_tiled_kernel(MsdaP p, MsdaTile g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vt[];
+    __shared__ int s_box[MSDT_L][4];                     // ymin, ymax, xmin, xmax of the taps on each level
+    __shared__ int s_part[6][MSDT_L][4];                 // ... per wave
+    __shared__ int s_lv[MSDT_L][8];                      // box origin (y, x), box width, LDS offset (-1: not staged), H, W, first pixel: read back per level in pass 2
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nth >> 6;
+    // workgroup -> (image, region, head): the M heads of a region are CONSECUTIVE workgroups of ONE XCD (hardware block i runs on XCD i % 8).
+    // Head m uses 96 of the 768 bytes of a query's sampling-location row and 64 of the 512 bytes of a value pixel: dispatched 128 workgroups
+    // apart on eight different XCDs, every head re-fetched the same lines from the fabric (pass 1 alone took 230 us of a 350 us launch).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int m = slot % p.M, unit = (slot / p.M) * 8 + xcd;
+    const int b = unit / g.nregions, region = unit - b * g.nregions;
+    if (b >= p.B) return;
+    if (g.variant & 4) return;
+    const int ry = region / g.ntx, rx = region - ry * g.ntx;
+    const int LP = p.L * p.P;
+    // this region's rectangle of queries on every level: [ceil(t0 * H_l / RH), ceil(t1 * H_l / RH)) partitions level l exactly
+    const int ty0 = ry * g.TY, ty1 = min(ty0 + g.TY, g.RH), tx0 = rx * g.TX, tx1 = min(tx0 + g.TX, g.RW);
+    int qy0[MSDT_L], qx0[MSDT_L], qw[MSDT_L], qend[MSDT_L];
+    int nq = 0;
+#pragma unroll
+    for (int l = 0; l < MSDT_L; ++l) {
+        qy0[l] = 0; qx0[l] = 0; qw[l] = 1; qend[l] = nq;
+        if (l < p.L) {
+            // (32-bit unsigned: the launcher keeps every extent below 32768; 64-bit divisions here were 2 800 instructions per wave)
+            const unsigned H0 = (unsigned)g.RH, W0 = (unsigned)g.RW, Hl = (unsigned)g.H[l], Wl = (unsigned)g.W[l];
+            const int y0 = (int)(((unsigned)ty0 * Hl + H0 - 1u) / H0), y1 = (int)(((unsigned)ty1 * Hl + H0 - 1u) / H0);
+            const int x0 = (int)(((unsigned)tx0 * Wl + W0 - 1u) / W0), x1 = (int)(((unsigned)tx1 * Wl + W0 - 1u) / W0);
+            qy0[l] = y0; qx0[l] = x0; qw[l] = max(x1 - x0, 1);
+            nq += max(y1 - y0, 0) * max(x1 - x0, 0);
+            qend[l] = nq;
+        }
+    }
+    if (tid < MSDT_L * 4) s_box[tid >> 2][tid & 3] = (tid & 1) ? -1 : 0x7fffffff;
+    __syncthreads();
+    auto query_of = [&](int idx) {                       // idx-th query of the region -> flat query index (selects: no dynamic indexing)
+        int first = 0, y0 = qy0[0], x0 = qx0[0], w = qw[0], st = g.start[0], Wl = g.W[0];
+#pragma unroll
+        for (int k = 0; k < MSDT_L - 1; ++k)
+            if (k + 1 < p.L && idx >= qend[k]) { first = qend[k]; y0 = qy0[k + 1]; x0 = qx0[k + 1]; w = qw[k + 1]; st = g.start[k + 1]; Wl = g.W[k + 1]; }
+        const int r = idx - first, yy = r / w, xx = r - yy * w;
+        return st + (y0 + yy) * Wl + x0 + xx;
+    };
+    // pass 1: bounding boxes of the valid taps
+    {
+        int bx[MSDT_L][4];
+#pragma unroll
+        for (int l = 0; l < MSDT_L; ++l) { bx[l][0] = 0x7fffffff; bx[l][1] = -1; bx[l][2] = 0x7fffffff; bx[l][3] = -1; }
+        for (int idx = tid; idx < nq; idx += nth) {
+            if (g.variant & 8) break;
+            const float* loc = p.loc + (((long)b * p.Lq + query_of(idx)) * p.M + m) * LP * 2;
+#pragma unroll
+            for (int l = 0; l < MSDT_L; ++l) {
+                if (l >= p.L) continue;
+                const int Hl = g.H[l], Wl = g.W[l];
+                auto one = [&](float x, float y) {
+                    const float him = y * Hl - 0.5f, wim = x * Wl - 0.5f;
+                    if (him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl) {
+                        const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+                        bx[l][0] = min(bx[l][0], max(h0, 0)); bx[l][1] = max(bx[l][1], min(h0 + 1, Hl - 1));
+                        bx[l][2] = min(bx[l][2], max(w0, 0)); bx[l][3] = max(bx[l][3], min(w0 + 1, Wl - 1));
+                    }
+                };
+                if (P4) {
+                    const float4 a = *(const float4*)(loc + l * 8), c = *(const float4*)(loc + l * 8 + 4);
+                    one(a.x, a.y); one(a.z, a.w); one(c.x, c.y); one(c.z, c.w);
+                } else {
+                    for (int k = 0; k < p.P; ++k) { const float2 xy = *(const float2*)(loc + (l * p.P + k) * 2); one(xy.x, xy.y); }
+                }
+            }
+        }
+        // workgroup-wide min / max WITHOUT LDS atomics: all 384 threads adding to the same 12 words serialised lane by lane (190 us of a
+        // 350 us launch).  Butterfly inside the wave, one row of partial results per wave, then 16 threads fold the rows.
+#pragma unroll
+        for (int l = 0; l < MSDT_L; ++l) {
+            if (l >= p.L) continue;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                bx[l][0] = min(bx[l][0], __shfl_xor(bx[l][0], o)); bx[l][1] = max(bx[l][1], __shfl_xor(bx[l][1], o));
+                bx[l][2] = min(bx[l][2], __shfl_xor(bx[l][2], o)); bx[l][3] = max(bx[l][3], __shfl_xor(bx[l][3], o));
+            }
+            if (lane == 0) { s_part[wave][l][0] = bx[l][0]; s_part[wave][l][1] = bx[l][1]; s_part[wave][l][2] = bx[l][2]; s_part[wave][l][3] = bx[l][3]; }
+        }
+    }
+    __syncthreads();
+    if (tid < MSDT_L * 4 && (tid >> 2) < p.L) {
+        const int l = tid >> 2, k = tid & 3;
+        int v = (k & 1) ? -1 : 0x7fffffff;
+        for (int w = 0; w < nwave; ++w) v = (k & 1) ? max(v, s_part[w][l][k]) : min(v, s_part[w][l][k]);
+        s_box[l][k] = v;
+    }
+    __syncthreads();
+    // LDS allocation (the same decision in every thread).  Boxes that fit the budget together are staged whole; otherwise every box is
+    // shrunk about its centre by one common factor (offsets that reach far leave most samples near the region all the same) and a sample
+    // whose four taps are not all inside its level's box is gathered from memory.
+    int by0[MSDT_L], bx0[MSDT_L], bw[MSDT_L], bh[MSDT_L], loff[MSDT_L];
+    {
+        long total = 0;
+#pragma unroll
+        for (int l = 0; l < MSDT_L; ++l) {
+            by0[l] = 0; bx0[l] = 0; bw[l] = 0; bh[l] = 0; loff[l] = -1;
+            if (l < p.L && __builtin_amdgcn_readfirstlane(s_box[l][1]) >= 0) {          // (readfirstlane: workgroup-uniform values, kept in SGPRs)
+                by0[l] = __builtin_amdgcn_readfirstlane(s_box[l][0]); bx0[l] = __builtin_amdgcn_readfirstlane(s_box[l][2]);
+                bh[l] = __builtin_amdgcn_readfirstlane(s_box[l][1]) - by0[l] + 1; bw[l] = __builtin_amdgcn_readfirstlane(s_box[l][3]) - bx0[l] + 1;
+                total += (long)bh[l] * bw[l] * 64;
+            }
+        }
+        const float f = total > g.lds_bytes ? sqrtf((float)g.lds_bytes / (float)total) * 0.98f : 1.f;
+        int off = 0;
+#pragma unroll
+        for (int l = 0; l < MSDT_L; ++l) {
+            if (bh[l] <= 0) continue;
+            if (f < 1.f) {
+                const int nh = max((int)((float)bh[l] * f), 1), nw = max((int)((float)bw[l] * f), 1);
+                by0[l] += (bh[l] - nh) >> 1; bx0[l] += (bw[l] - nw) >> 1; bh[l] = nh; bw[l] = nw;
+            }
+            const int bytes = bh[l] * bw[l] * 64;
+            if (off + bytes <= g.lds_bytes) { loff[l] = off; off += bytes; }
+        }
+    }
+    if (tid < MSDT_L) {
+#pragma unroll
+        for (int l = 0; l < MSDT_L; ++l)
+            if (tid == l) { s_lv[l][0] = by0[l]; s_lv[l][1] = bx0[l]; s_lv[l][2] = bw[l]; s_lv[l][3] = loff[l]; s_lv[l][4] = g.H[l]; s_lv[l][5] = g.W[l]; s_lv[l][6] = g.start[l]; s_lv[l][7] = bh[l]; }
+    }
+    const long vstride = (long)p.M * 32;
+    const bf16* vbase = (const bf16*)p.value + (long)b * p.S * vstride + (long)m * 32;
+    // staging by LDS-DMA (global_load_lds_dwordx4: no registers, every piece of the boxes in flight at once -- a load / ds_write loop paid
+    // one L2 round trip per 6 KB).  The DMA writes lane-linearly (wave base + 16 * lane): a wave takes 16 pixels x 4 chunks of one box row,
+    // and the slot swizzle is applied to the SOURCE chunk each lane fetches.
+    typedef __attribute__((address_space(3))) void lds_void;
+    if (!(g.variant & 1)) {
+#pragma unroll
+        for (int l = 0; l < MSDT_L; ++l) {
+            if (loff[l] < 0) continue;
+            const bf16* lv = vbase + ((long)g.start[l] + (long)by0[l] * g.W[l] + bx0[l]) * vstride;
+            const int rowchunks = bw[l] * 4;
+            for (int row = wave; row < bh[l]; row += nwave)
+                for (int j0 = 0; j0 < rowchunks; j0 += 64) {
+                    const int j = j0 + lane;
+                    if (j < rowchunks) {
+                        const int px = j >> 2, pix = row * bw[l] + px, c = (j & 3) ^ ((pix >> 2) & 3);
+                        __builtin_amdgcn_global_load_lds(lv + ((long)row * g.W[l] + px) * vstride + c * 8,
+                                                         (lds_void*)(vt + loff[l] + (row * rowchunks + j0) * 16), 16, 0, 0);
+                    }
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces have landed
+    }
+    __syncthreads();
+    if (g.variant & 2) return;
+    // pass 2: the samples
+    for (int idx = tid; idx < nq; idx += nth) {
+        const int q = query_of(idx);
+        const long grp = ((long)b * p.Lq + q) * p.M + m;
+        const float* loc = p.loc + grp * LP * 2;
+        const float* aw = p.attn + grp * LP;
+        float acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int l = 0; l < p.L; ++l) {                  // (not unrolled: one copy of the sample body; the level's constants come back from LDS as scalars)
+            const int Hl = __builtin_amdgcn_readfirstlane(s_lv[l][4]), Wl = __builtin_amdgcn_readfirstlane(s_lv[l][5]);
+            const int lstart = __builtin_amdgcn_readfirstlane(s_lv[l][6]);
+            const int lby0 = __builtin_amdgcn_readfirstlane(s_lv[l][0]), lbx0 = __builtin_amdgcn_readfirstlane(s_lv[l][1]);
+            const int lbw = __builtin_amdgcn_readfirstlane(s_lv[l][2]), lloff = __builtin_amdgcn_readfirstlane(s_lv[l][3]);
+            const int lbh = __builtin_amdgcn_readfirstlane(s_lv[l][7]);
+            float4 a, c, ww;                             // the level's four locations and weights: one round trip per level
+            if (P4) { a = *(const float4*)(loc + l * 8); c = *(const float4*)(loc + l * 8 + 4); ww = *(const float4*)(aw + l * 4); }
+            auto sample = [&](float sx, float sy, float w) {
+                const float him = sy * Hl - 0.5f, wim = sx * Wl - 0.5f;
+                if (!(him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl)) return;
+                const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+                const float lh = him - h0, lw = wim - w0, hh = 1.f - lh, hw = 1.f - lw;
+                const bool y0ok = h0 >= 0, y1ok = h0 + 1 <= Hl - 1, x0ok = w0 >= 0, x1ok = w0 + 1 <= Wl - 1;
+                // a tap outside the map keeps weight 0 and reads the (clamped) neighbouring pixel instead: its bits are multiplied by 0
+                const float w1 = (y0ok && x0ok) ? hh * hw * w : 0.f, w2 = (y0ok && x1ok) ? hh * lw * w : 0.f;
+                const float w3 = (y1ok && x0ok) ? lh * hw * w : 0.f, w4 = (y1ok && x1ok) ? lh * lw * w : 0.f;
+                const int ya = max(h0, 0), yb = min(h0 + 1, Hl - 1), xa = max(w0, 0), xb = min(w0 + 1, Wl - 1);
+                if (lloff >= 0 && ya >= lby0 && yb < lby0 + lbh && xa >= lbx0 && xb < lbx0 + lbw) {
+                    const unsigned char* tb = vt + lloff;
+                    const int i1 = (ya - lby0) * lbw + (xa - lbx0), i2 = (ya - lby0) * lbw + (xb - lbx0);
+                    const int i3 = (yb - lby0) * lbw + (xa - lbx0), i4 = (yb - lby0) * lbw + (xb - lbx0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x4 v1 = *(const u32x4*)(tb + i1 * 64 + ((c ^ ((i1 >> 2) & 3)) << 4));
+                        const u32x4 v2 = *(const u32x4*)(tb + i2 * 64 + ((c ^ ((i2 >> 2) & 3)) << 4));
+                        const u32x4 v3 = *(const u32x4*)(tb + i3 * 64 + ((c ^ ((i3 >> 2) & 3)) << 4));
+                        const u32x4 v4 = *(const u32x4*)(tb + i4 * 64 + ((c ^ ((i4 >> 2) & 3)) << 4));
+                        msdt_fma8(v1, v2, v3, v4, w1, w2, w3, w4, acc + 8 * c);
+                        if (c == 1) __builtin_amdgcn_sched_barrier(0);      // at most 8 of the 16 tap reads in flight (32 registers)
+                    }
+                } else {
+                    const bf16* lv = vbase + (long)lstart * vstride;
+                    const bf16* p1 = lv + ((long)ya * Wl + xa) * vstride; const bf16* p2 = lv + ((long)ya * Wl + xb) * vstride;
+                    const bf16* p3 = lv + ((long)yb * Wl + xa) * vstride; const bf16* p4 = lv + ((long)yb * Wl + xb) * vstride;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        msdt_fma8(*(const u32x4*)(p1 + c * 8), *(const u32x4*)(p2 + c * 8), *(const u32x4*)(p3 + c * 8), *(const u32x4*)(p4 + c * 8), w1, w2, w3, w4,
+                                  acc + 8 * c);
+                }
+            };
+            if (P4) {
+                // one copy of the sample body per level (selects instead of four inlined copies: those kept 16 LDS reads x 4 samples live and spilled)
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k)
+                    sample(k == 0 ? a.x : k == 1 ? a.z : k == 2 ? c.x : c.z, k == 0 ? a.y : k == 1 ? a.w : k == 2 ? c.y : c.w,
+                           k == 0 ? ww.x : k == 1 ? ww.y : k == 2 ? ww.z : ww.w);
+            } else {
+                for (int k = 0; k < p.P; ++k) {
+                    const float2 xy = *(const float2*)(loc + (l * p.P + k) * 2);
+                    sample(xy.x, xy.y, aw[l * p.P + k]);
+                }
+            }
+        }
+        const long o = grp * 32;
+        if (p.out_f32) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(float4*)((float*)p.out + o + 4 * i) = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x8 ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = (bf16)acc[8 * i + j];
+                *(bf16x8*)((bf16*)p.out + o + 8 * i) = ov;
+            }
+        }
+    }
+}
+
 // ---- backward, direct: D lanes per (b,q,m) (D = 16, 32 or 64), lane = channel, every tap one float atomic -------------
 struct MsdaTap {       // geometry of one sample on its level
     int h0, w0;
@@ -610,6 +875,64 @@ extern "C" int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int6
     if (D == 32) hipLaunchKernelGGL((msda_fwd_kernel<8, false>), dim3(grid), dim3(256), 0, stream, p);
     else if (D == 16) hipLaunchKernelGGL((msda_fwd_kernel<4, false>), dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((msda_fwd_kernel<16, false>), dim3(grid), dim3(256), 0, stream, p);
+    UENC_LAUNCH_RET();
+}
+
+// The forward for the encoder's geometry (Lq == S: query i IS pixel i of the level-major maps), value tiles in LDS; same arguments
+// and results as uenc_msdeform_attn_fwd plus the host copy of `shapes` (the grid is cut from the level-0 map).  Returns UENC_EINVAL
+// -- nothing launched -- when the geometry is not the encoder's (Lq != S, D != 32, fp32 value, L > 4, L * P > 16): the caller then
+// uses uenc_msdeform_attn_fwd.
+extern "C" int uenc_msdeform_attn_fwd_tiled(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
+                                            const float* loc, const float* attn, void* out, int out_dtype, int B, int S, int M,
+                                            int D, int L, int Lq, int P, const int64_t* shapes_host, hipStream_t stream) {
+    MsdaP p;
+    int rc = msda_fill(p, value, v_dtype, shapes, level_start, loc, attn, B, S, M, D, L, Lq, P);
+    if (rc != UENC_OK) return rc;
+    UENC_CHECK_ARG(out && shapes_host && D == 32 && v_dtype == UENC_BF16 && Lq == S && L <= MSDT_L && L * P <= 16 && (long)B * M < 65536 && (long)B * S * M < (1L << 31) / 64);
+    UENC_CHECK_ARG(((uintptr_t)out & 15) == 0 && ((uintptr_t)loc & 7) == 0);
+    p.out = out; p.out_f32 = (out_dtype == UENC_F32);
+    MsdaTile g;
+    long start = 0;
+    for (int l = 0; l < MSDT_L; ++l) {
+        g.H[l] = 1; g.W[l] = 1; g.start[l] = 0;
+        if (l >= L) continue;
+        const long Hl = shapes_host[2 * l], Wl = shapes_host[2 * l + 1];
+        UENC_CHECK_ARG(Hl > 0 && Wl > 0 && Hl < 32768 && Wl < 32768);
+        g.H[l] = (int)Hl; g.W[l] = (int)Wl; g.start[l] = (int)start;
+        start += Hl * Wl;
+    }
+    UENC_CHECK_ARG(start == S);                                          // level-major, nothing else in the sequence
+    int ty = 8, tx = 32, kb = 78;                                        // UENC_MSDA_TILE = "TY,TX,KB" (tuning / tests; read per call)
+    {
+        const char* e = getenv("UENC_MSDA_TILE");
+        if (e && (sscanf(e, "%d,%d,%d", &ty, &tx, &kb) != 3 || ty < 1 || tx < 1 || kb < 1 || kb > 156)) { ty = 8; tx = 32; kb = 78; }
+    }
+    static int lds_max = 0;
+    if (kb * 1024 > lds_max) {
+        hipError_t er = hipFuncSetAttribute((const void*)msda_fwd_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
+        if (er == hipSuccess) er = hipFuncSetAttribute((const void*)msda_fwd_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
+        if (er != hipSuccess) return (int)er;
+        lds_max = kb * 1024;
+    }
+    g.TY = ty; g.TX = tx; g.lds_bytes = kb * 1024;
+    { const char* e = getenv("UENC_MSDA_VARIANT"); g.variant = e ? atoi(e) : 0; }
+    g.RH = g.H[0]; g.RW = g.W[0];
+    for (int l = 1; l < L; ++l)
+        if ((long)g.H[l] * g.W[l] > (long)g.RH * g.RW) { g.RH = g.H[l]; g.RW = g.W[l]; }
+    const int nty = (g.RH + g.TY - 1) / g.TY;
+    g.ntx = (g.RW + g.TX - 1) / g.TX;
+    // queries per region (the finest level's rectangle + the other levels' share): threads = that, rounded to waves, at most 384
+    long per = 0;
+    for (int l = 0; l < L; ++l) per += ((long)g.TY * g.H[l] / g.RH + 1) * ((long)g.TX * g.W[l] / g.RW + 1);
+    int threads = (int)((per + 63) / 64 * 64);
+    threads = threads < 64 ? 64 : (threads > 384 ? 384 : threads);
+    if (P == 4 && ((uintptr_t)loc & 15) == 0 && ((uintptr_t)attn & 15) == 0)
+    g.nregions = nty * g.ntx;
+    const unsigned grid = (unsigned)(((long)B * g.nregions + 7) / 8 * 8 * M);
+    if (P == 4 && ((uintptr_t)loc & 15) == 0 && ((uintptr_t)attn & 15) == 0)
+        hipLaunchKernelGGL(msda_fwd_tiled_kernel<true>, dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
+    else
+        hipLaunchKernelGGL(msda_fwd_tiled_kernel<false>, dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
     UENC_LAUNCH_RET();
 }
 

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "uenc_window_attn_bwd_groups": [c_i, c_i, c_i, c_i, c_i],
     "uenc_window_attn_dtable_grouped": [c_p, c_i, c_i, c_p],
     "uenc_msdeform_attn_fwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_msdeform_attn_fwd_tiled": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "uenc_msdeform_attn_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p],
     "uenc_msdeform_attn_bwd_workspace_bytes": [c_p, c_i, c_i, c_i, c_i, c_i, c_i],
     "uenc_msdeform_attn_fused_fwd": [c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -538,9 +538,19 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
     return dqkv
 
 
-def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.float32):
+def msdeform_tiled_eligible(value, shapes_host, Lq: int, L: int, P: int) -> bool:
+    """Geometry of the deformable encoder (queries = the pixels of the L maps): the LDS-tiled forward applies."""
+    if shapes_host is None or os.environ.get("UENC_MSDA_TILED", "1") == "0":
+        return False
+    B, S, M, D = value.shape
+    return (D == 32 and value.dtype == torch.bfloat16 and L <= 4 and L * P <= 16 and Lq == S and B * M < 65536
+            and sum(int(h) * int(w) for h, w in shapes_host) == S)
+
+
+def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.float32, shapes_host=None):
     """value (B,S,M,D) fp32|bf16, shapes (L,2) int64, level_start (L) int64, loc (B,Lq,M,L,P,2), attn (B,Lq,M,L,P)
-    -> (B, Lq, M*D).  Same tensor contract as the reference's ms_deform_attn_forward."""
+    -> (B, Lq, M*D).  Same tensor contract as the reference's ms_deform_attn_forward.  shapes_host: optional [(H, W), ...] host copy
+    of `shapes`; with it the encoder's geometry (Lq == S) takes the LDS-tiled kernel (same result)."""
     B, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     for t in (value, shapes, level_start, loc, attn):
@@ -549,6 +559,14 @@ def msdeform_attn_fwd(value, shapes, level_start, loc, attn, out_dtype=torch.flo
     assert shapes.dtype == torch.int64 and level_start.dtype == torch.int64
     assert loc.dtype == torch.float32 and attn.dtype == torch.float32 and attn.shape == (B, Lq, M, L, P)
     out = torch.empty((B, Lq, M * D), dtype=_odt(out_dtype), device=value.device)
+    if msdeform_tiled_eligible(value, shapes_host, Lq, L, P):
+        import ctypes
+        flat = [int(v) for hw in shapes_host for v in hw]
+        sh = (ctypes.c_int64 * len(flat))(*flat)
+        check(lib.uenc_msdeform_attn_fwd_tiled(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(),
+                                               attn.data_ptr(), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, sh, stream_ptr()),
+              "msdeform_attn_fwd_tiled")
+        return out
     check(lib.uenc_msdeform_attn_fwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(),
                                      attn.data_ptr(), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, stream_ptr()),
           "msdeform_attn_fwd")

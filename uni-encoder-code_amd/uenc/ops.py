@@ -924,7 +924,8 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         # (the forward keeps the glue kernel + core pair: the fused forward measured 5 % SLOWER at the pixel decoder's size, the fused
         # backward 7-8 % faster -- tools/msda_fused_bench.py; it recomputes locations / weights from the saved projection row)
         loc, aw = K.msda_prep_fwd(offaw, ref, shapes, B, S, nH, L, nP)
-        att = K.msdeform_attn_fwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, out_dtype=BF16).view(M, C)
+        # (shapes_host: the queries are the maps' own pixels here, so the forward stages the sampled value pixels in LDS)
+        att = K.msdeform_attn_fwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, out_dtype=BF16, shapes_host=shapes_host).view(M, C)
         if fused:
             loc, aw = offaw, ref
         if drop is None or K.EXACT:
@@ -1053,10 +1054,10 @@ class MSDeformAttnFunction(torch.autograd.Function):
                 raise RuntimeError("Not implemented on the CPU")        # ms_deform_attn.h:43
             if not t.is_contiguous():
                 raise RuntimeError("tensor has to be contiguous")        # ms_deform_attn_cuda.cu:33-37
+        ctx.shapes_host = _host_shapes(value_spatial_shapes)        # lets the backward bin grad_value per block of pixels (and the forward tile)
         out = K.msdeform_attn_fwd(value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                                  attention_weights, out_dtype=out_dtype or (F32 if value.dtype == F32 else BF16))
+                                  attention_weights, out_dtype=out_dtype or (F32 if value.dtype == F32 else BF16), shapes_host=ctx.shapes_host)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
-        ctx.shapes_host = _host_shapes(value_spatial_shapes)        # lets the backward bin grad_value per block of pixels
         return out
 
     @staticmethod
