@@ -577,3 +577,38 @@ def test_msdeform_fwd_tiled_equals_gather(K, shapes_l, spread, tile, monkeypatch
         assert float((got.float() - want.float()).abs().max()) <= tol * den, (odt, float((got.float() - want.float()).abs().max()), den)
     # not the encoder's geometry: the wrapper must keep the gather kernel (fewer queries than pixels)
     assert not K.msdeform_tiled_eligible(value, shapes_l, S - 1, L, P)
+
+
+@pytest.mark.parametrize("shapes_l,spread,tile", [([(4, 8), (8, 16), (16, 32)], 3.0, None), ([(7, 11), (13, 22), (27, 43)], 6.0, "8,16,30"),
+                                                  ([(27, 43), (13, 22), (7, 11)], 40.0, "8,24,6"), ([(9, 5)], 3.0, "4,4,1"),
+                                                  ([(33, 70), (17, 35), (9, 18), (5, 9)], 5.0, None)])
+def test_msdeform_fused_bwd_tiled_equals_one_kernel(K, shapes_l, spread, tile, monkeypatch):
+    """The fused backward with d(offaw) from the LDS-tiled kernel + append-only binned kernel (encoder geometry) against the one-kernel form
+    (UENC_MSDA_TILED_BWD=0) on the same inputs: d(offaw) within one bf16 ulp of the largest entries, grad_value within the float-atomics
+    order -- staged, partially staged and unstaged levels, samples outside the maps, 1 / 3 / 4 levels in both orders, fp32 and bf16 grad_out."""
+    L, P, M, D, B = len(shapes_l), 4, 8, 32, 2
+    S = sum(h * w for h, w in shapes_l)
+    gen = torch.Generator().manual_seed(21)
+    ref1 = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1).reshape(-1, 2).flip(-1)
+                      for h, w in shapes_l])
+    ref = ref1[None, :, None, :].expand(1, S, L, 2).contiguous().cuda()
+    ncol = 3 * M * L * P
+    offaw = torch.zeros(B * S, ncol)
+    offaw[:, : 2 * M * L * P] = (torch.rand(B * S, 2 * M * L * P, generator=gen) * 2 - 1) * spread
+    offaw[:, 2 * M * L * P:] = torch.randn(B * S, M * L * P, generator=gen) * 2
+    offaw = offaw.cuda()
+    value = torch.randn(B, S, M, D, generator=gen).to(torch.bfloat16).cuda()
+    shapes = torch.tensor(shapes_l, dtype=torch.int64).cuda()
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    if tile is not None:
+        monkeypatch.setenv("UENC_MSDA_TILE_BWD", tile)
+    for godt in (torch.bfloat16, torch.float32):
+        go = torch.randn(B, S, M * D, generator=gen).to(godt).cuda()
+        monkeypatch.setenv("UENC_MSDA_TILED_BWD", "0")
+        gv0, d0 = K.msdeform_attn_fused_bwd(value, shapes, start, offaw, ref, L, P, go, shapes_l)
+        monkeypatch.setenv("UENC_MSDA_TILED_BWD", "1")
+        gv1, d1 = K.msdeform_attn_fused_bwd(value, shapes, start, offaw, ref, L, P, go, shapes_l)
+        _close(gv1, gv0, 2e-5 * float(gv0.abs().max()) + 1e-6, 1e-4)
+        den = float(d0.float().abs().max())
+        assert float((d1.float() - d0.float()).abs().max()) <= 2 ** -7 * den
+        assert float((d1.float() - d0.float()).norm() / d0.float().norm()) < 2e-3

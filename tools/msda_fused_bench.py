@@ -33,3 +33,8 @@ def pair_b():
     return K.msda_prep_bwd(gl, ga, aw, shapes, ncol)
 print(f"forward : prep + core {timeit(lambda: pair_f()):8.1f} us   fused {timeit(lambda: K.msdeform_attn_fused_fwd(value, shapes, start, offaw, ref, L, P, out_dtype=torch.bfloat16)):8.1f} us")
 print(f"backward: core + prep {timeit(pair_b):8.1f} us   fused {timeit(lambda: K.msdeform_attn_fused_bwd(value, shapes, start, offaw, ref, L, P, go, shapes_l)):8.1f} us")
+os.environ["UENC_MSDA_TILED_BWD"] = "0"
+t0 = timeit(lambda: K.msdeform_attn_fused_bwd(value, shapes, start, offaw, ref, L, P, go, shapes_l))
+os.environ["UENC_MSDA_TILED_BWD"] = "1"
+t1 = timeit(lambda: K.msdeform_attn_fused_bwd(value, shapes, start, offaw, ref, L, P, go, shapes_l))
+print(f"fused backward: one gather kernel {t0:8.1f} us   LDS-tiled gather + append-only bins {t1:8.1f} us")

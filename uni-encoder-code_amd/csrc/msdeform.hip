@@ -147,8 +147,19 @@ __device__ __forceinline__ void msdt_fma8(const u32x4& a, const u32x4& b, const 
 // P4: P == 4 -- a level's four locations / weights are three 16-byte loads, and all levels' loads are requested before the first sample is
 // used (with a run-time P every sample's location was a dependent global load in front of its LDS reads: 12 exposed L2 round trips per
 // query, and the kernel ran 1.5 x SLOWER than the gather kernel it replaces).
-template <bool P4>
-__global__ __launch_bounds__(384, 3) void msda_fwd_tiled_kernel(MsdaP p, MsdaTile g) {
+// BWD: the gather half of the backward in the fused form (uenc_msdeform_attn_fused_bwd; P == 4): locations and softmaxed weights are
+// derived from the projection row `offaw` as in msda_bwd_bin_kernel<true>, the thread dots the 32 channels of its query's grad_out row
+// with the four taps of every sample and writes d(offaw) -- the grad_value half stays with the binned kernels.
+__device__ __forceinline__ void msdt_dot8(const u32x4& v, const float* t8, float& d) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d += t8[2 * i] * __uint_as_float(v[i] << 16) + t8[2 * i + 1] * __uint_as_float(v[i] & 0xffff0000u);
+}
+
+// (the backward form keeps 32 grad_out channels, the samples' results and the tap reads live: ~220 registers, so it runs 256-thread
+// workgroups at two waves per SIMD on 8 x 24 regions -- 252 queries -- where the forward runs 384 threads at three on 8 x 32)
+template <bool P4, bool BWD>
+__global__ __launch_bounds__(BWD ? 256 : 384, BWD ? 2 : 3) void msda_tiled_kernel(MsdaP p, MsdaTile g) {
+    static_assert(P4 || !BWD, "the backward form is built for P == 4");
     extern __shared__ __attribute__((aligned(16))) unsigned char vt[];
     __shared__ int s_box[MSDT_L][4];                     // ymin, ymax, xmin, xmax of the taps on each level
     __shared__ int s_part[6][MSDT_L][4];                 // ... per wave
@@ -191,6 +202,19 @@ __global__ __launch_bounds__(384, 3) void msda_fwd_tiled_kernel(MsdaP p, MsdaTil
         const int r = idx - first, yy = r / w, xx = r - yy * w;
         return st + (y0 + yy) * Wl + x0 + xx;
     };
+    // the four sampling locations (x, y) x 4 of level l of a query: read (forward) or derived from the projection row (backward)
+    auto level_xy = [&](long row, int l, int Hl, int Wl, float4& a, float4& c) {
+        if (BWD) {
+            const float* off = p.offaw + row * p.ld + (long)m * LP * 2 + l * 8;
+            const float4 o0 = *(const float4*)off, o1 = *(const float4*)(off + 4);
+            const float2 rf = *(const float2*)(p.ref + ((p.ref_per_image ? row : row % p.Lq) * p.L + l) * 2);
+            a = make_float4(rf.x + o0.x / (float)Wl, rf.y + o0.y / (float)Hl, rf.x + o0.z / (float)Wl, rf.y + o0.w / (float)Hl);
+            c = make_float4(rf.x + o1.x / (float)Wl, rf.y + o1.y / (float)Hl, rf.x + o1.z / (float)Wl, rf.y + o1.w / (float)Hl);
+        } else {
+            const float* loc = p.loc + (row * p.M + m) * LP * 2 + l * 8;
+            a = *(const float4*)loc; c = *(const float4*)(loc + 4);
+        }
+    };
     // pass 1: bounding boxes of the valid taps
     {
         int bx[MSDT_L][4];
@@ -198,7 +222,8 @@ __global__ __launch_bounds__(384, 3) void msda_fwd_tiled_kernel(MsdaP p, MsdaTil
         for (int l = 0; l < MSDT_L; ++l) { bx[l][0] = 0x7fffffff; bx[l][1] = -1; bx[l][2] = 0x7fffffff; bx[l][3] = -1; }
         for (int idx = tid; idx < nq; idx += nth) {
             if (g.variant & 8) break;
-            const float* loc = p.loc + (((long)b * p.Lq + query_of(idx)) * p.M + m) * LP * 2;
+            const long row1 = (long)b * p.Lq + query_of(idx);
+            const float* loc = BWD ? nullptr : p.loc + (row1 * p.M + m) * LP * 2;
 #pragma unroll
             for (int l = 0; l < MSDT_L; ++l) {
                 if (l >= p.L) continue;
@@ -212,7 +237,8 @@ __global__ __launch_bounds__(384, 3) void msda_fwd_tiled_kernel(MsdaP p, MsdaTil
                     }
                 };
                 if (P4) {
-                    const float4 a = *(const float4*)(loc + l * 8), c = *(const float4*)(loc + l * 8 + 4);
+                    float4 a, c;
+                    level_xy(row1, l, Hl, Wl, a, c);
                     one(a.x, a.y); one(a.z, a.w); one(c.x, c.y); one(c.z, c.w);
                 } else {
                     for (int k = 0; k < p.P; ++k) { const float2 xy = *(const float2*)(loc + (l * p.P + k) * 2); one(xy.x, xy.y); }
@@ -299,6 +325,125 @@ __global__ __launch_bounds__(384, 3) void msda_fwd_tiled_kernel(MsdaP p, MsdaTil
     }
     __syncthreads();
     if (g.variant & 2) return;
+    if (BWD) {
+        // pass 2 (backward): d(offaw) of every (query, head) of the region
+        for (int idx = tid; idx < nq; idx += nth) {
+            const long row = (long)b * p.Lq + query_of(idx);
+            float top[32];
+            if (p.go_f32) {
+                const float* gp = (const float*)p.grad_out + (row * p.M + m) * 32;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float4 t = *(const float4*)(gp + 4 * i); top[4 * i] = t.x; top[4 * i + 1] = t.y; top[4 * i + 2] = t.z; top[4 * i + 3] = t.w; }
+            } else {
+                const bf16* gp = (const bf16*)p.grad_out + (row * p.M + m) * 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x4 t = *(const u32x4*)(gp + 8 * i);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { top[8 * i + 2 * r] = __uint_as_float(t[r] << 16); top[8 * i + 2 * r + 1] = __uint_as_float(t[r] & 0xffff0000u); }
+                }
+            }
+            // softmax over the L * 4 logits of this (query, head)
+            const float* lg = p.offaw + row * p.ld + (long)p.M * LP * 2 + (long)m * LP;
+            // (named registers, not arrays: the level loop below is not unrolled and the compiler turns selects over array elements back
+            // into dynamic indexing, i.e. scratch; the exponentials are recomputed per level from the L1-resident logits instead of kept)
+            float mx, inv;
+            {
+                const float4 lz = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+                const float4 e0 = *(const float4*)lg, e1 = p.L > 1 ? *(const float4*)(lg + 4) : lz, e2 = p.L > 2 ? *(const float4*)(lg + 8) : lz,
+                             e3 = p.L > 3 ? *(const float4*)(lg + 12) : lz;
+                auto max4 = [](const float4& v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); };
+                mx = fmaxf(fmaxf(max4(e0), max4(e1)), fmaxf(max4(e2), max4(e3)));
+                auto sum4 = [&](const float4& v) { return __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx); };
+                inv = 1.0f / (sum4(e0) + sum4(e1) + sum4(e2) + sum4(e3));          // (absent levels: exp(-3e38 - mx) = 0)
+            }
+            auto aw_of = [&](int l) {
+                const float4 v = *(const float4*)(lg + 4 * l);
+                return make_float4(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv, __expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+            };
+            bf16* drow = p.doffaw + row * p.ldd;
+            float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0, u3 = u0;      // aw * d(aw) per sample
+            float dot = 0.f;
+#pragma unroll 1
+            for (int l = 0; l < p.L; ++l) {               // (not unrolled: four inlined copies of the sample body spilled 450 bytes; selects pick the level's registers)
+                const int Hl = __builtin_amdgcn_readfirstlane(s_lv[l][4]), Wl = __builtin_amdgcn_readfirstlane(s_lv[l][5]);
+                const int lstart = __builtin_amdgcn_readfirstlane(s_lv[l][6]);
+                const int lby0 = __builtin_amdgcn_readfirstlane(s_lv[l][0]), lbx0 = __builtin_amdgcn_readfirstlane(s_lv[l][1]);
+                const int lbw = __builtin_amdgcn_readfirstlane(s_lv[l][2]), lloff = __builtin_amdgcn_readfirstlane(s_lv[l][3]);
+                const int lbh = __builtin_amdgcn_readfirstlane(s_lv[l][7]);
+                float4 a, c;
+                level_xy(row, l, Hl, Wl, a, c);
+                const float4 aw4 = aw_of(l);
+                float4 ul = make_float4(0.f, 0.f, 0.f, 0.f), dW = ul, dH = ul;
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    const float sx = k == 0 ? a.x : k == 1 ? a.z : k == 2 ? c.x : c.z, sy = k == 0 ? a.y : k == 1 ? a.w : k == 2 ? c.y : c.w;
+                    const float w = k == 0 ? aw4.x : k == 1 ? aw4.y : k == 2 ? aw4.z : aw4.w;
+                    float g_w = 0.f, g_h = 0.f, g_a = 0.f;
+                    const float him = sy * Hl - 0.5f, wim = sx * Wl - 0.5f;
+                    if (him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl) {
+                        const int h0 = (int)floorf(him), w0 = (int)floorf(wim);
+                        const float lh = him - h0, lw = wim - w0, hh = 1.f - lh, hw = 1.f - lw;
+                        const bool y0ok = h0 >= 0, y1ok = h0 + 1 <= Hl - 1, x0ok = w0 >= 0, x1ok = w0 + 1 <= Wl - 1;
+                        const int ya = max(h0, 0), yb = min(h0 + 1, Hl - 1), xa = max(w0, 0), xb = min(w0 + 1, Wl - 1);
+                        float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
+                        if (lloff >= 0 && ya >= lby0 && yb < lby0 + lbh && xa >= lbx0 && xb < lbx0 + lbw) {
+                            const unsigned char* tb = vt + lloff;
+                            const int i1 = (ya - lby0) * lbw + (xa - lbx0), i2 = (ya - lby0) * lbw + (xb - lbx0);
+                            const int i3 = (yb - lby0) * lbw + (xa - lbx0), i4 = (yb - lby0) * lbw + (xb - lbx0);
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) {
+                                msdt_dot8(*(const u32x4*)(tb + i1 * 64 + ((cc ^ ((i1 >> 2) & 3)) << 4)), top + 8 * cc, d1);
+                                msdt_dot8(*(const u32x4*)(tb + i2 * 64 + ((cc ^ ((i2 >> 2) & 3)) << 4)), top + 8 * cc, d2);
+                                msdt_dot8(*(const u32x4*)(tb + i3 * 64 + ((cc ^ ((i3 >> 2) & 3)) << 4)), top + 8 * cc, d3);
+                                msdt_dot8(*(const u32x4*)(tb + i4 * 64 + ((cc ^ ((i4 >> 2) & 3)) << 4)), top + 8 * cc, d4);
+                                if (cc & 1) __builtin_amdgcn_sched_barrier(0);      // 8 of the 16 tap reads in flight at a time (32 registers)
+                            }
+                        } else {
+                            const bf16* lv = vbase + (long)lstart * vstride;
+                            const bf16* p1 = lv + ((long)ya * Wl + xa) * vstride; const bf16* p2 = lv + ((long)ya * Wl + xb) * vstride;
+                            const bf16* p3 = lv + ((long)yb * Wl + xa) * vstride; const bf16* p4 = lv + ((long)yb * Wl + xb) * vstride;
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) {
+                                msdt_dot8(*(const u32x4*)(p1 + cc * 8), top + 8 * cc, d1); msdt_dot8(*(const u32x4*)(p2 + cc * 8), top + 8 * cc, d2);
+                                msdt_dot8(*(const u32x4*)(p3 + cc * 8), top + 8 * cc, d3); msdt_dot8(*(const u32x4*)(p4 + cc * 8), top + 8 * cc, d4);
+                                if (cc & 1) __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        // taps outside the map carry nothing (their reads were clamped to a neighbour)
+                        if (!(y0ok && x0ok)) d1 = 0.f;
+                        if (!(y0ok && x1ok)) d2 = 0.f;
+                        if (!(y1ok && x0ok)) d3 = 0.f;
+                        if (!(y1ok && x1ok)) d4 = 0.f;
+                        g_a = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
+                        g_w = (float)Wl * w * (-hh * d1 + hh * d2 - lh * d3 + lh * d4);
+                        g_h = (float)Hl * w * (-hw * d1 - lw * d2 + hw * d3 + lw * d4);
+                    }
+                    const float ua = w * g_a, ox = g_w / (float)Wl, oy = g_h / (float)Hl;
+                    if (k == 0) { ul.x = ua; dW.x = ox; dH.x = oy; } else if (k == 1) { ul.y = ua; dW.y = ox; dH.y = oy; }
+                    else if (k == 2) { ul.z = ua; dW.z = ox; dH.z = oy; } else { ul.w = ua; dW.w = ox; dH.w = oy; }
+                }
+                if (l == 0) u0 = ul; else if (l == 1) u1 = ul; else if (l == 2) u2 = ul; else u3 = ul;
+                dot += ul.x + ul.y + ul.z + ul.w;
+                bf16x8 o8;
+                o8[0] = (bf16)dW.x; o8[1] = (bf16)dH.x; o8[2] = (bf16)dW.y; o8[3] = (bf16)dH.y;
+                o8[4] = (bf16)dW.z; o8[5] = (bf16)dH.z; o8[6] = (bf16)dW.w; o8[7] = (bf16)dH.w;
+                *(bf16x8*)(drow + (long)m * LP * 2 + l * 8) = o8;
+            }
+            auto put = [&](int l, const float4& uu) {        // d(logit) = aw * (d(aw) - sum aw d(aw))
+                const float4 ee = aw_of(l);
+                bf16x4 o4;
+                o4[0] = (bf16)(uu.x - ee.x * dot); o4[1] = (bf16)(uu.y - ee.y * dot);
+                o4[2] = (bf16)(uu.z - ee.z * dot); o4[3] = (bf16)(uu.w - ee.w * dot);
+                *(bf16x4*)(drow + (long)p.M * LP * 2 + (long)m * LP + 4 * l) = o4;
+            };
+            put(0, u0);
+            if (p.L > 1) put(1, u1);
+            if (p.L > 2) put(2, u2);
+            if (p.L > 3) put(3, u3);
+        }
+        return;
+    }
     // pass 2: the samples
     for (int idx = tid; idx < nq; idx += nth) {
         const int q = query_of(idx);
@@ -500,6 +645,7 @@ struct MsdaBins {
     long rtot;                                           // record slots per (image, head)
     int nblk, nwork;                                     // bins / pass-B work items per (image, head)
     int variant;                                         // timing experiments only (UENC_MSDA_VARIANT), 0 in production
+    int append_only;                                     // 1: d(loc) / d(attn) come from the LDS-tiled kernel; this one writes records (and adds what overflows)
     int* count;                                          // [B * M * nblk] x MSDA_CNT_STRIDE ints (zeroed by the launcher)
     int2* rec_hd;                                        // [B * M][rtot]
     float4* rec_w;                                       // [B * M][rtot]
@@ -633,6 +779,8 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
     }
     const bool any_ovf = __ballot(ovfbits != 0u) != 0ull;       // wave-uniform: the shuffles below are skipped when nothing overflowed
     if (!live || bn.variant == 2) return;
+    const bool gather = bn.append_only == 0;
+    if (!gather && !any_ovf) return;
 
     // ---- gather phase: lane = 4 channels ----
     const int gl0 = (tid & 63) & ~7;           // first lane of this group within the wave
@@ -656,10 +804,12 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
                 const long r1 = r0 + (long)Wl * vstride;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 v1 = z, v2 = z, v3 = z, v4 = z;
-                if (t.y0ok && t.x0ok) v1 = ldv4(p.value, p.v_f32, r0);
-                if (t.y0ok && t.x1ok) v2 = ldv4(p.value, p.v_f32, r0 + vstride);
-                if (t.y1ok && t.x0ok) v3 = ldv4(p.value, p.v_f32, r1);
-                if (t.y1ok && t.x1ok) v4 = ldv4(p.value, p.v_f32, r1 + vstride);
+                if (gather) {
+                    if (t.y0ok && t.x0ok) v1 = ldv4(p.value, p.v_f32, r0);
+                    if (t.y0ok && t.x1ok) v2 = ldv4(p.value, p.v_f32, r0 + vstride);
+                    if (t.y1ok && t.x0ok) v3 = ldv4(p.value, p.v_f32, r1);
+                    if (t.y1ok && t.x1ok) v4 = ldv4(p.value, p.v_f32, r1 + vstride);
+                }
                 if (o4) {
                     const int oy1 = (t.y0ok && ((t.h0 + 1) / MSDA_BS) == (t.h0 / MSDA_BS)) ? 0 : 1;     // owner row / column of the second taps
                     const int ox1 = (t.x0ok && ((t.w0 + 1) / MSDA_BS) == (t.w0 / MSDA_BS)) ? 0 : 1;
@@ -684,6 +834,7 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
             }
         }
     }
+    if (!gather) return;
     if (FUSED) {
         // d(offaw) straight from the group's registers: d(offset) = d(loc) / (W_l, H_l), d(logit) = aw * (d(aw) - sum_s aw d(aw))
         // (the arithmetic of msda_prep_kernel<true>); lanes write consecutive 4- / 2-byte pieces of the row: coalesced runs
@@ -844,6 +995,7 @@ static int msda_plan_bins(const int64_t* shapes_host, int L, int Lq, int P, int 
     bn.nblk = off;
     bn.nwork = woff;
     bn.rtot = roff;
+    bn.append_only = 0;
     return 1;
 }
 
@@ -878,6 +1030,50 @@ extern "C" int uenc_msdeform_attn_fwd(const void* value, int v_dtype, const int6
     UENC_LAUNCH_RET();
 }
 
+// Region grid of the LDS-tiled kernels: levels from the host copy of `shapes`, regions cut from the finest map.
+static int msda_tile_setup(MsdaTile& g, const int64_t* shapes_host, int B, int S, int M, int L, bool bwd, unsigned& grid, int& threads) {
+    long start = 0;
+    for (int l = 0; l < MSDT_L; ++l) {
+        g.H[l] = 1; g.W[l] = 1; g.start[l] = 0;
+        if (l >= L) continue;
+        const long Hl = shapes_host[2 * l], Wl = shapes_host[2 * l + 1];
+        UENC_CHECK_ARG(Hl > 0 && Wl > 0 && Hl < 32768 && Wl < 32768);
+        g.H[l] = (int)Hl; g.W[l] = (int)Wl; g.start[l] = (int)start;
+        start += Hl * Wl;
+    }
+    UENC_CHECK_ARG(start == S);                                          // level-major, nothing else in the sequence
+    int ty = 8, tx = bwd ? 24 : 32, kb = 78;                             // UENC_MSDA_TILE[_BWD] = "TY,TX,KB" (tuning / tests; read per call)
+    {
+        const char* e = getenv(bwd ? "UENC_MSDA_TILE_BWD" : "UENC_MSDA_TILE");
+        if (e && (sscanf(e, "%d,%d,%d", &ty, &tx, &kb) != 3 || ty < 1 || tx < 1 || kb < 1 || kb > 156)) { ty = 8; tx = bwd ? 24 : 32; kb = 78; }
+    }
+    static int lds_max = 0;
+    if (kb * 1024 > lds_max) {
+        const void* fns[3] = {(const void*)msda_tiled_kernel<true, false>, (const void*)msda_tiled_kernel<false, false>, (const void*)msda_tiled_kernel<true, true>};
+        for (int i = 0; i < 3; ++i) {
+            hipError_t er = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
+            if (er != hipSuccess) return (int)er;
+        }
+        lds_max = kb * 1024;
+    }
+    g.TY = ty; g.TX = tx; g.lds_bytes = kb * 1024;
+    { const char* e = getenv("UENC_MSDA_VARIANT"); g.variant = e ? atoi(e) : 0; }
+    g.RH = g.H[0]; g.RW = g.W[0];
+    for (int l = 1; l < L; ++l)
+        if ((long)g.H[l] * g.W[l] > (long)g.RH * g.RW) { g.RH = g.H[l]; g.RW = g.W[l]; }
+    const int nty = (g.RH + g.TY - 1) / g.TY;
+    g.ntx = (g.RW + g.TX - 1) / g.TX;
+    g.nregions = nty * g.ntx;
+    // queries per region (the finest level's rectangle + the other levels' share): threads = that, rounded to waves, at most 384
+    long per = 0;
+    for (int l = 0; l < L; ++l) per += ((long)g.TY * g.H[l] / g.RH + 1) * ((long)g.TX * g.W[l] / g.RW + 1);
+    threads = (int)((per + 63) / 64 * 64);
+    const int tmax = bwd ? 256 : 384;
+    threads = threads < 64 ? 64 : (threads > tmax ? tmax : threads);
+    grid = (unsigned)(((long)B * g.nregions + 7) / 8 * 8 * M);
+    return UENC_OK;
+}
+
 // The forward for the encoder's geometry (Lq == S: query i IS pixel i of the level-major maps), value tiles in LDS; same arguments
 // and results as uenc_msdeform_attn_fwd plus the host copy of `shapes` (the grid is cut from the level-0 map).  Returns UENC_EINVAL
 // -- nothing launched -- when the geometry is not the encoder's (Lq != S, D != 32, fp32 value, L > 4, L * P > 16): the caller then
@@ -892,47 +1088,13 @@ extern "C" int uenc_msdeform_attn_fwd_tiled(const void* value, int v_dtype, cons
     UENC_CHECK_ARG(((uintptr_t)out & 15) == 0 && ((uintptr_t)loc & 7) == 0);
     p.out = out; p.out_f32 = (out_dtype == UENC_F32);
     MsdaTile g;
-    long start = 0;
-    for (int l = 0; l < MSDT_L; ++l) {
-        g.H[l] = 1; g.W[l] = 1; g.start[l] = 0;
-        if (l >= L) continue;
-        const long Hl = shapes_host[2 * l], Wl = shapes_host[2 * l + 1];
-        UENC_CHECK_ARG(Hl > 0 && Wl > 0 && Hl < 32768 && Wl < 32768);
-        g.H[l] = (int)Hl; g.W[l] = (int)Wl; g.start[l] = (int)start;
-        start += Hl * Wl;
-    }
-    UENC_CHECK_ARG(start == S);                                          // level-major, nothing else in the sequence
-    int ty = 8, tx = 32, kb = 78;                                        // UENC_MSDA_TILE = "TY,TX,KB" (tuning / tests; read per call)
-    {
-        const char* e = getenv("UENC_MSDA_TILE");
-        if (e && (sscanf(e, "%d,%d,%d", &ty, &tx, &kb) != 3 || ty < 1 || tx < 1 || kb < 1 || kb > 156)) { ty = 8; tx = 32; kb = 78; }
-    }
-    static int lds_max = 0;
-    if (kb * 1024 > lds_max) {
-        hipError_t er = hipFuncSetAttribute((const void*)msda_fwd_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
-        if (er == hipSuccess) er = hipFuncSetAttribute((const void*)msda_fwd_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
-        if (er != hipSuccess) return (int)er;
-        lds_max = kb * 1024;
-    }
-    g.TY = ty; g.TX = tx; g.lds_bytes = kb * 1024;
-    { const char* e = getenv("UENC_MSDA_VARIANT"); g.variant = e ? atoi(e) : 0; }
-    g.RH = g.H[0]; g.RW = g.W[0];
-    for (int l = 1; l < L; ++l)
-        if ((long)g.H[l] * g.W[l] > (long)g.RH * g.RW) { g.RH = g.H[l]; g.RW = g.W[l]; }
-    const int nty = (g.RH + g.TY - 1) / g.TY;
-    g.ntx = (g.RW + g.TX - 1) / g.TX;
-    // queries per region (the finest level's rectangle + the other levels' share): threads = that, rounded to waves, at most 384
-    long per = 0;
-    for (int l = 0; l < L; ++l) per += ((long)g.TY * g.H[l] / g.RH + 1) * ((long)g.TX * g.W[l] / g.RW + 1);
-    int threads = (int)((per + 63) / 64 * 64);
-    threads = threads < 64 ? 64 : (threads > 384 ? 384 : threads);
+    unsigned grid = 0; int threads = 0;
+    rc = msda_tile_setup(g, shapes_host, B, S, M, L, false, grid, threads);
+    if (rc != UENC_OK) return rc;
     if (P == 4 && ((uintptr_t)loc & 15) == 0 && ((uintptr_t)attn & 15) == 0)
-    g.nregions = nty * g.ntx;
-    const unsigned grid = (unsigned)(((long)B * g.nregions + 7) / 8 * 8 * M);
-    if (P == 4 && ((uintptr_t)loc & 15) == 0 && ((uintptr_t)attn & 15) == 0)
-        hipLaunchKernelGGL(msda_fwd_tiled_kernel<true>, dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
+        hipLaunchKernelGGL((msda_tiled_kernel<true, false>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
     else
-        hipLaunchKernelGGL(msda_fwd_tiled_kernel<false>, dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
+        hipLaunchKernelGGL((msda_tiled_kernel<false, false>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
     UENC_LAUNCH_RET();
 }
 
@@ -1047,7 +1209,17 @@ extern "C" int uenc_msdeform_attn_fused_bwd(const void* value, int v_dtype, cons
     bn.rec_hd = (int2*)((char*)workspace + cnt_bytes + (long)B * M * bn.rtot * 16);
     hipError_t e = hipMemsetAsync(bn.count, 0, (size_t)cnt_bytes, stream);
     if (e != hipSuccess) return (int)e;
+    // encoder geometry (queries = the maps' pixels, P == 4, 16-byte aligned rows): d(offaw) from the LDS-tiled kernel, the binned kernel only
+    // appends its records.  UENC_MSDA_TILED_BWD=0: the one-kernel form (A/B).
+    bool tiled = Lq == S && P == 4 && L <= MSDT_L && v_dtype == UENC_BF16 && (long)B * M < 65536 && (long)B * S * M < (1L << 31) / 64 &&
+                 ((uintptr_t)offaw & 15) == 0 && ld % 4 == 0 && ((uintptr_t)doffaw & 15) == 0 && ld_doffaw % 8 == 0 && ((uintptr_t)ref & 7) == 0;
+    { const char* ev = getenv("UENC_MSDA_TILED_BWD"); if (ev && atoi(ev) == 0) tiled = false; }
+    MsdaTile g;
+    unsigned tgrid = 0; int tthreads = 0;
+    if (tiled && msda_tile_setup(g, shapes_host, B, S, M, L, true, tgrid, tthreads) != UENC_OK) tiled = false;
+    bn.append_only = tiled ? 1 : 0;
     hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
+    if (tiled) hipLaunchKernelGGL((msda_tiled_kernel<true, true>), dim3(tgrid), dim3(tthreads), g.lds_bytes, stream, p, g);
     if (p.go_f32) hipLaunchKernelGGL(msda_bin_reduce_kernel<true>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
     else hipLaunchKernelGGL(msda_bin_reduce_kernel<false>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
     UENC_LAUNCH_RET();
