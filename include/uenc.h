@@ -266,6 +266,11 @@ long uenc_msdeform_attn_bwd_workspace_bytes(const int64_t* shapes_host, int B, i
 int uenc_msdeform_attn_fused_fwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
                                  long ld, const float* ref, int ref_per_image, void* out, int out_dtype, int B, int S, int M, int D,
                                  int L, int Lq, int P, uenc_stream_t stream);
+/* The fused forward for the encoder's geometry with the value tiles in LDS (uenc_msdeform_attn_fwd_tiled with the locations / weights derived
+ * inside the kernel): P == 4, ld % 4 == 0, 16-byte aligned offaw / out; -1 (nothing launched) when not eligible. */
+int uenc_msdeform_attn_fused_fwd_tiled(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
+                                       long ld, const float* ref, int ref_per_image, void* out, int out_dtype, int B, int S, int M, int D,
+                                       int L, int Lq, int P, const int64_t* shapes_host, uenc_stream_t stream);
 int uenc_msdeform_attn_fused_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
                                  long ld, const float* ref, int ref_per_image, const void* grad_out, int go_dtype, float* grad_value,
                                  void* doffaw, long ld_doffaw, int B, int S, int M, int D, int L, int Lq, int P, const int64_t* shapes_host,

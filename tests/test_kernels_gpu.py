@@ -577,6 +577,19 @@ def test_msdeform_fwd_tiled_equals_gather(K, shapes_l, spread, tile, monkeypatch
         assert float((got.float() - want.float()).abs().max()) <= tol * den, (odt, float((got.float() - want.float()).abs().max()), den)
     # not the encoder's geometry: the wrapper must keep the gather kernel (fewer queries than pixels)
     assert not K.msdeform_tiled_eligible(value, shapes_l, S - 1, L, P)
+    # the fused tiled forward (locations / weights derived in the kernel from the projection row) against glue kernel + gather kernel
+    Mh = M
+    ncol = 3 * Mh * L * P
+    offaw = torch.zeros(B * S, ncol + 4)
+    offaw[:, : 2 * Mh * L * P] = (torch.rand(B * S, 2 * Mh * L * P, generator=gen) * 2 - 1) * spread
+    offaw[:, 2 * Mh * L * P: ncol] = torch.randn(B * S, Mh * L * P, generator=gen) * 2
+    offaw = offaw.cuda()[:, :ncol]                                                              # padded rows (ld = ncol + 4)
+    refd = ref[None, :, None, :].expand(1, S, L, 2).contiguous().cuda()
+    loc2, aw2 = K.msda_prep_fwd(offaw, refd, shapes, B, S, Mh, L, P)
+    want = K.msdeform_attn_fwd(value, shapes, start, loc2, aw2, out_dtype=torch.bfloat16)
+    got = K.msdeform_attn_fused_fwd(value, shapes, start, offaw, refd, L, P, out_dtype=torch.bfloat16, shapes_host=shapes_l)
+    den = float(want.float().abs().max())
+    assert float((got.float() - want.float()).abs().max()) <= 2 ** -8 * den
 
 
 @pytest.mark.parametrize("shapes_l,spread,tile", [([(4, 8), (8, 16), (16, 32)], 3.0, None), ([(7, 11), (13, 22), (27, 43)], 6.0, "8,16,30"),

@@ -157,9 +157,12 @@ __device__ __forceinline__ void msdt_dot8(const u32x4& v, const float* t8, float
 
 // (the backward form keeps 32 grad_out channels, the samples' results and the tap reads live: ~220 registers, so it runs 256-thread
 // workgroups at two waves per SIMD on 8 x 24 regions -- 252 queries -- where the forward runs 384 threads at three on 8 x 32)
-template <bool P4, bool BWD>
-__global__ __launch_bounds__(BWD ? 256 : 384, BWD ? 2 : 3) void msda_tiled_kernel(MsdaP p, MsdaTile g) {
-    static_assert(P4 || !BWD, "the backward form is built for P == 4");
+// MODE 0: forward from sampling locations / attention weights; 1: the backward above; 2: forward from the projection row (no msda_prep pass,
+// no loc / attn tensors: the fused forward the backward has had all along).
+template <bool P4, int MODE>
+__global__ __launch_bounds__(MODE == 1 ? 256 : 384, MODE == 1 ? 2 : 3) void msda_tiled_kernel(MsdaP p, MsdaTile g) {
+    constexpr bool BWD = MODE == 1, FUSED_IN = MODE != 0;
+    static_assert(P4 || !FUSED_IN, "the fused forms are built for P == 4");
     extern __shared__ __attribute__((aligned(16))) unsigned char vt[];
     __shared__ int s_box[MSDT_L][4];                     // ymin, ymax, xmin, xmax of the taps on each level
     __shared__ int s_part[6][MSDT_L][4];                 // ... per wave
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(BWD ? 256 : 384, BWD ? 2 : 3) void msda_tiled_kerne
     };
     // the four sampling locations (x, y) x 4 of level l of a query: read (forward) or derived from the projection row (backward)
     auto level_xy = [&](long row, int l, int Hl, int Wl, float4& a, float4& c) {
-        if (BWD) {
+        if (FUSED_IN) {
             const float* off = p.offaw + row * p.ld + (long)m * LP * 2 + l * 8;
             const float4 o0 = *(const float4*)off, o1 = *(const float4*)(off + 4);
             const float2 rf = *(const float2*)(p.ref + ((p.ref_per_image ? row : row % p.Lq) * p.L + l) * 2);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(BWD ? 256 : 384, BWD ? 2 : 3) void msda_tiled_kerne
         for (int idx = tid; idx < nq; idx += nth) {
             if (g.variant & 8) break;
             const long row1 = (long)b * p.Lq + query_of(idx);
-            const float* loc = BWD ? nullptr : p.loc + (row1 * p.M + m) * LP * 2;
+            const float* loc = FUSED_IN ? nullptr : p.loc + (row1 * p.M + m) * LP * 2;
 #pragma unroll
             for (int l = 0; l < MSDT_L; ++l) {
                 if (l >= p.L) continue;
@@ -448,8 +451,20 @@ __global__ __launch_bounds__(BWD ? 256 : 384, BWD ? 2 : 3) void msda_tiled_kerne
     for (int idx = tid; idx < nq; idx += nth) {
         const int q = query_of(idx);
         const long grp = ((long)b * p.Lq + q) * p.M + m;
-        const float* loc = p.loc + grp * LP * 2;
-        const float* aw = p.attn + grp * LP;
+        const float* loc = FUSED_IN ? nullptr : p.loc + grp * LP * 2;
+        const float* aw = FUSED_IN ? nullptr : p.attn + grp * LP;
+        const long frow = (long)b * p.Lq + q;
+        const float* flg = p.offaw + frow * p.ld + (long)p.M * LP * 2 + (long)m * LP;       // FUSED_IN: this (query, head)'s L * 4 logits
+        float fmx = 0.f, finv = 0.f;
+        if (FUSED_IN) {
+            const float4 lz = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            const float4 e0 = *(const float4*)flg, e1 = p.L > 1 ? *(const float4*)(flg + 4) : lz, e2 = p.L > 2 ? *(const float4*)(flg + 8) : lz,
+                         e3 = p.L > 3 ? *(const float4*)(flg + 12) : lz;
+            auto max4 = [](const float4& v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); };
+            fmx = fmaxf(fmaxf(max4(e0), max4(e1)), fmaxf(max4(e2), max4(e3)));
+            auto sum4 = [&](const float4& v) { return __expf(v.x - fmx) + __expf(v.y - fmx) + __expf(v.z - fmx) + __expf(v.w - fmx); };
+            finv = 1.0f / (sum4(e0) + sum4(e1) + sum4(e2) + sum4(e3));
+        }
         float acc[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc[i] = 0.f;
@@ -461,7 +476,11 @@ __global__ __launch_bounds__(BWD ? 256 : 384, BWD ? 2 : 3) void msda_tiled_kerne
             const int lbw = __builtin_amdgcn_readfirstlane(s_lv[l][2]), lloff = __builtin_amdgcn_readfirstlane(s_lv[l][3]);
             const int lbh = __builtin_amdgcn_readfirstlane(s_lv[l][7]);
             float4 a, c, ww;                             // the level's four locations and weights: one round trip per level
-            if (P4) { a = *(const float4*)(loc + l * 8); c = *(const float4*)(loc + l * 8 + 4); ww = *(const float4*)(aw + l * 4); }
+            if (FUSED_IN) {
+                level_xy(frow, l, Hl, Wl, a, c);
+                const float4 v = *(const float4*)(flg + 4 * l);
+                ww = make_float4(__expf(v.x - fmx) * finv, __expf(v.y - fmx) * finv, __expf(v.z - fmx) * finv, __expf(v.w - fmx) * finv);
+            } else if (P4) { a = *(const float4*)(loc + l * 8); c = *(const float4*)(loc + l * 8 + 4); ww = *(const float4*)(aw + l * 4); }
             auto sample = [&](float sx, float sy, float w) {
                 const float him = sy * Hl - 0.5f, wim = sx * Wl - 0.5f;
                 if (!(him > -1.f && wim > -1.f && him < (float)Hl && wim < (float)Wl)) return;
@@ -1049,8 +1068,9 @@ static int msda_tile_setup(MsdaTile& g, const int64_t* shapes_host, int B, int S
     }
     static int lds_max = 0;
     if (kb * 1024 > lds_max) {
-        const void* fns[3] = {(const void*)msda_tiled_kernel<true, false>, (const void*)msda_tiled_kernel<false, false>, (const void*)msda_tiled_kernel<true, true>};
-        for (int i = 0; i < 3; ++i) {
+        const void* fns[4] = {(const void*)msda_tiled_kernel<true, 0>, (const void*)msda_tiled_kernel<false, 0>, (const void*)msda_tiled_kernel<true, 1>,
+                              (const void*)msda_tiled_kernel<true, 2>};
+        for (int i = 0; i < 4; ++i) {
             hipError_t er = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024);
             if (er != hipSuccess) return (int)er;
         }
@@ -1092,9 +1112,9 @@ extern "C" int uenc_msdeform_attn_fwd_tiled(const void* value, int v_dtype, cons
     rc = msda_tile_setup(g, shapes_host, B, S, M, L, false, grid, threads);
     if (rc != UENC_OK) return rc;
     if (P == 4 && ((uintptr_t)loc & 15) == 0 && ((uintptr_t)attn & 15) == 0)
-        hipLaunchKernelGGL((msda_tiled_kernel<true, false>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
+        hipLaunchKernelGGL((msda_tiled_kernel<true, 0>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
     else
-        hipLaunchKernelGGL((msda_tiled_kernel<false, false>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
+        hipLaunchKernelGGL((msda_tiled_kernel<false, 0>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
     UENC_LAUNCH_RET();
 }
 
@@ -1183,6 +1203,27 @@ extern "C" int uenc_msdeform_attn_fused_fwd(const void* value, int v_dtype, cons
     UENC_LAUNCH_RET();
 }
 
+// The fused forward for the encoder's geometry, value tiles in LDS (see uenc_msdeform_attn_fwd_tiled): locations and softmaxed weights are
+// derived inside the kernel, so neither uenc_msda_prep_fwd nor its two tensors exist.  Needs P == 4, 16-byte aligned offaw rows (ld % 4 == 0);
+// returns -1 (nothing launched) when the geometry is not eligible -- call uenc_msdeform_attn_fused_fwd then.
+extern "C" int uenc_msdeform_attn_fused_fwd_tiled(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start, const float* offaw,
+                                                  long ld, const float* ref, int ref_per_image, void* out, int out_dtype, int B, int S, int M, int D,
+                                                  int L, int Lq, int P, const int64_t* shapes_host, hipStream_t stream) {
+    MsdaP p;
+    int rc = msda_fill_fused(p, value, v_dtype, shapes, level_start, offaw, ld, ref, ref_per_image, B, S, M, D, L, Lq, P);
+    if (rc != UENC_OK) return rc;
+    UENC_CHECK_ARG(out && shapes_host && D == 32 && v_dtype == UENC_BF16 && Lq == S && L <= MSDT_L && P == 4 && (long)B * M < 65536 &&
+                   (long)B * S * M < (1L << 31) / 64);
+    UENC_CHECK_ARG(((uintptr_t)out & 15) == 0 && ((uintptr_t)offaw & 15) == 0 && ld % 4 == 0 && ((uintptr_t)ref & 7) == 0);
+    p.out = out; p.out_f32 = (out_dtype == UENC_F32);
+    MsdaTile g;
+    unsigned grid = 0; int threads = 0;
+    rc = msda_tile_setup(g, shapes_host, B, S, M, L, false, grid, threads);
+    if (rc != UENC_OK) return rc;
+    hipLaunchKernelGGL((msda_tiled_kernel<true, 2>), dim3(grid), dim3(threads), g.lds_bytes, stream, p, g);
+    UENC_LAUNCH_RET();
+}
+
 extern "C" int uenc_msdeform_attn_fused_bwd(const void* value, int v_dtype, const int64_t* shapes, const int64_t* level_start,
                                             const float* offaw, long ld, const float* ref, int ref_per_image, const void* grad_out,
                                             int go_dtype, float* grad_value, void* doffaw, long ld_doffaw, int B, int S, int M, int D, int L, int Lq, int P,
@@ -1219,7 +1260,7 @@ extern "C" int uenc_msdeform_attn_fused_bwd(const void* value, int v_dtype, cons
     if (tiled && msda_tile_setup(g, shapes_host, B, S, M, L, true, tgrid, tthreads) != UENC_OK) tiled = false;
     bn.append_only = tiled ? 1 : 0;
     hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, dim3((unsigned)(nchunk * B * M)), dim3(256), 0, stream, p, bn);
-    if (tiled) hipLaunchKernelGGL((msda_tiled_kernel<true, true>), dim3(tgrid), dim3(tthreads), g.lds_bytes, stream, p, g);
+    if (tiled) hipLaunchKernelGGL((msda_tiled_kernel<true, 1>), dim3(tgrid), dim3(tthreads), g.lds_bytes, stream, p, g);
     if (p.go_f32) hipLaunchKernelGGL(msda_bin_reduce_kernel<true>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
     else hipLaunchKernelGGL(msda_bin_reduce_kernel<false>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p, bn);
     UENC_LAUNCH_RET();

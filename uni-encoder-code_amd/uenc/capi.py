@@ -60,6 +60,7 @@ _SIGNATURES = {
     "uenc_msdeform_attn_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p],
     "uenc_msdeform_attn_bwd_workspace_bytes": [c_p, c_i, c_i, c_i, c_i, c_i, c_i],
     "uenc_msdeform_attn_fused_fwd": [c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "uenc_msdeform_attn_fused_fwd_tiled": [c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "uenc_msdeform_attn_fused_bwd": [c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_i, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p],
     "uenc_mha_fwd_workspace_floats": [c_i, c_i, c_i, c_i],
     "uenc_mha_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],

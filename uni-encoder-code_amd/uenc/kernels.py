@@ -618,12 +618,21 @@ def msdeform_fused_available(shapes_host, B, M, D, L, Lq, P) -> bool:
     return (not EXACT) and D == 32 and L * P <= 16 and shapes_host is not None and _msda_host_plan(shapes_host, B, M, D, L, Lq, P)[1] > 0
 
 
-def msdeform_attn_fused_fwd(value, shapes, level_start, offaw, ref, L: int, P: int, out_dtype=torch.bfloat16):
-    """value (B, S, M, D), offaw (B * Lq, ld) fp32 = [M][L][P][2] offsets | [M][L * P] logits, ref (B | 1, Lq, L, 2) -> (B, Lq, M * D)."""
+def msdeform_attn_fused_fwd(value, shapes, level_start, offaw, ref, L: int, P: int, out_dtype=torch.bfloat16, shapes_host=None):
+    """value (B, S, M, D), offaw (B * Lq, ld) fp32 = [M][L][P][2] offsets | [M][L * P] logits, ref (B | 1, Lq, L, 2) -> (B, Lq, M * D).
+    shapes_host: optional host copy of `shapes`; with it the encoder's geometry (Lq == S, P == 4) takes the LDS-tiled kernel (same result)."""
     B, S, M, D = value.shape
     Lq = ref.shape[1]
     assert offaw.dtype == torch.float32 and offaw.stride(1) == 1 and offaw.shape[0] == B * Lq and ref.dtype == torch.float32 and ref.is_contiguous()
     out = torch.empty((B, Lq, M * D), dtype=_odt(out_dtype), device=value.device)
+    if (P == 4 and offaw.stride(0) % 4 == 0 and offaw.data_ptr() % 16 == 0 and msdeform_tiled_eligible(value, shapes_host, Lq, L, P)):
+        import ctypes
+        flat = [int(v) for hw in shapes_host for v in hw]
+        sh = (ctypes.c_int64 * len(flat))(*flat)
+        check(lib.uenc_msdeform_attn_fused_fwd_tiled(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), offaw.data_ptr(), offaw.stride(0),
+                                                     ref.data_ptr(), int(ref.shape[0] != 1), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, sh, stream_ptr()),
+              "msdeform_attn_fused_fwd_tiled")
+        return out
     check(lib.uenc_msdeform_attn_fused_fwd(value.data_ptr(), dt(value), shapes.data_ptr(), level_start.data_ptr(), offaw.data_ptr(), offaw.stride(0),
                                            ref.data_ptr(), int(ref.shape[0] != 1), out.data_ptr(), dt(out), B, S, M, D, L, Lq, P, stream_ptr()),
           "msdeform_attn_fused_fwd")

@@ -921,13 +921,19 @@ class DeformEncoderLayerFn(torch.autograd.Function):
         # fused: sampling locations / softmaxed weights are derived inside the attention kernels from the projection row (no loc / aw tensors,
         # no glue kernels); UENC_MSDA_FUSED=0 keeps the module-by-module pair (A/B, and the form every other configuration takes)
         fused = os.environ.get("UENC_MSDA_FUSED", "1") != "0" and K.msdeform_fused_available(shapes_host, B, nH, D, L, S, nP)
-        # (the forward keeps the glue kernel + core pair: the fused forward measured 5 % SLOWER at the pixel decoder's size, the fused
-        # backward 7-8 % faster -- tools/msda_fused_bench.py; it recomputes locations / weights from the saved projection row)
-        loc, aw = K.msda_prep_fwd(offaw, ref, shapes, B, S, nH, L, nP)
-        # (shapes_host: the queries are the maps' own pixels here, so the forward stages the sampled value pixels in LDS)
-        att = K.msdeform_attn_fwd(value.view(B, S, nH, D), shapes, level_start, loc, aw, out_dtype=BF16, shapes_host=shapes_host).view(M, C)
-        if fused:
+        # (the general gather kernel keeps the glue kernel + core pair in the forward -- its fused form measured 5 % slower, tools/msda_fused_bench.py;
+        # the backward recomputes locations / weights from the saved projection row)
+        v4 = value.view(B, S, nH, D)
+        if (fused and nP == 4 and offaw.stride(0) % 4 == 0 and K.msdeform_tiled_eligible(v4, shapes_host, S, L, nP)
+                and os.environ.get("UENC_MSDA_FUSED_FWD", "1") != "0"):
+            # the queries are the maps' own pixels: the LDS-tiled kernel derives locations / weights itself (no glue kernel, no loc / aw tensors)
+            att = K.msdeform_attn_fused_fwd(v4, shapes, level_start, offaw, ref, L, nP, out_dtype=BF16, shapes_host=shapes_host).view(M, C)
             loc, aw = offaw, ref
+        else:
+            loc, aw = K.msda_prep_fwd(offaw, ref, shapes, B, S, nH, L, nP)
+            att = K.msdeform_attn_fwd(v4, shapes, level_start, loc, aw, out_dtype=BF16, shapes_host=shapes_host).view(M, C)
+            if fused:
+                loc, aw = offaw, ref
         if drop is None or K.EXACT:
             assert drop is None, "the fp32 verification mode has no dropout path"
             h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
