@@ -16,7 +16,7 @@ def first(name):
 wall = (seg[-1][1] - t0) / 1e6
 busy = sum(e - s for s, e, n in seg) / 1e6
 print(f"step wall {wall:.2f} ms  busy {busy:.2f} ms  launches {len(seg)}")
-marks = [('fwd backbone', 0.0), ('fwd pixel decoder', first('msda_prep')), ('fwd transformer decoder + upsample', first('mha_q_kernel<0')),
+marks = [('fwd backbone', 0.0), ('fwd pixel decoder', first('msda_')), ('fwd transformer decoder + upsample', first('mha_q_kernel<0')),
          ('bwd transformer decoder', first('mha_dkdv')), ('bwd pixel decoder', first('msda_bwd_bin')), ('bwd backbone', first('wattn_bwd'))]
 marks = [(n, t) for n, t in marks if t is not None] + [('end', 1e18)]
 for (name, lo), (_, hi) in zip(marks, marks[1:]):
