@@ -316,6 +316,13 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
     unsigned char* Vs = Ks + 2 * KB * 64;
     float* lse = (float*)(Vs + 2 * KB * 64);
     float* delta = lse + nslices * MQ;
+    // Mask tile of the current 64-key block, TRANSPOSED: row = key, NQ + 4 bytes per row (an odd number of dwords: the 16 keys of a wave
+    // fall into 16 banks), byte q = 1 when query q may not see the key (rows of the padding queries are all 1).  A lane then reads the
+    // mask of its key for four consecutive queries as ONE LDS dword; loading the bytes from memory one by one inside the score loop
+    // (8 dependent L2 round trips per 32 queries, each behind its own s_waitcnt) made the masked launches 2.4 x slower per key than
+    // the unmasked ones.
+    unsigned char* Ms = (unsigned char*)(delta + nslices * MQ);
+    const int MSTR = nslices * MQ + 4;
 
     int split, bh;
     if (!mha_decode_block(p, split, bh)) return;
@@ -327,6 +334,26 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
     const bf16* kb = p.k + b * p.k_bs + h * 32;
     const bf16* vb = p.v + b * p.v_bs + h * 32;
     const int NQ = nslices * MQ;
+    const bool masked = p.mask != nullptr;
+    // mask staging: dword d of the tile = (query d >> 4, keys 4 (d & 15) .. + 3); MREG dwords per thread cover 160 queries, more slices loop
+    constexpr int MREG = MQ * 16 / 256;
+    unsigned mreg[MREG];
+    auto mload = [&](int blk, int pass) {
+#pragma unroll
+        for (int i = 0; i < MREG; ++i) {
+            const int d = pass * MQ * 16 + threadIdx.x + 256 * i, q = d >> 4, kk = k_begin + blk * KB + 4 * (d & 15);
+            mreg[i] = 0x01010101u;                      // padding queries / keys past the end: blocked
+            if (q < p.Lq && kk < p.S) mreg[i] = *(const unsigned*)(p.mask + ((long)b * p.Lq + q) * p.mask_rs + kk);
+        }
+    };
+    auto mstore = [&](int pass) {
+#pragma unroll
+        for (int i = 0; i < MREG; ++i) {
+            const int d = pass * MQ * 16 + threadIdx.x + 256 * i, q = d >> 4, c4 = 4 * (d & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ms[(c4 + j) * MSTR + q] = (unsigned char)((mreg[i] >> (8 * j)) & 0xffu);
+        }
+    };
 
     stage_rows(Qs, p.q + b * p.q_bs + h * 32, p.q_rs, 0, NQ, p.Lq, 256);
     stage_rows(dOs, p.dout + b * p.do_bs + h * 32, p.do_rs, 0, NQ, p.Lq, 256);
@@ -360,6 +387,8 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
         *(u32x4*)(Vs + st * KB * 64 + rm_off(srow, sch)) = rv;
     };
     if (nblk > 0) { gload(0); lstore(0); }
+    if (masked && nblk > 0)
+        for (int pass = 0; pass < nslices; ++pass) { mload(0, pass); mstore(pass); }
     __syncthreads();
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -367,6 +396,7 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
     for (int blk = 0; blk < nblk; ++blk) {
         const int st = blk & 1;
         if (blk + 1 < nblk) gload(blk + 1);
+        if (masked && blk + 1 < nblk && nslices == 1) mload(blk + 1, 0);       // (one slice -- every shipped configuration: the next tile waits in registers)
         const unsigned char* Kc = Ks + st * KB * 64;
         const unsigned char* Vc = Vs + st * KB * 64;
         const int key = k_begin + blk * KB + wave * 16 + fr;           // this lane's key (column)
@@ -383,11 +413,13 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
                 const float4 l4 = *(const float4*)(lse + qt * 16 + 4 * fg);
                 const float4 d4 = *(const float4*)(delta + qt * 16 + 4 * fg);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+                unsigned mw = 0u;
+                if (masked) mw = *(const unsigned*)(Ms + (wave * 16 + fr) * MSTR + qt * 16 + 4 * fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qt * 16 + 4 * fg + r;
                     bool ok = (key < k_end) && (qi < p.Lq);
-                    if (ok && p.mask != nullptr) ok = p.mask[((long)b * p.Lq + qi) * p.mask_rs + key] == 0;
+                    if (masked) ok = ok && ((mw >> (8 * r)) & 0xffu) == 0u;
                     const float pr = ok ? fast_exp2(sv[r] * sc - lv[r]) : 0.f;
                     float keepw = 1.0f;
                     if (DROP && ok)
@@ -419,6 +451,11 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
             }
         }
         if (blk + 1 < nblk) lstore(st ^ 1);
+        if (masked && blk + 1 < nblk) {
+            __syncthreads();                            // every wave is done with this block's mask tile
+            if (nslices == 1) mstore(0);
+            else for (int pass = 0; pass < nslices; ++pass) { mload(blk + 1, pass); mstore(pass); }
+        }
         __syncthreads();
     }
 }
@@ -507,7 +544,7 @@ extern "C" int uenc_mha_bwd(const void* q, long q_bs, long q_rs, const void* k, 
     const int slices = (Lq + MQ - 1) / MQ;
     if (p.drop_thresh != 0u) hipLaunchKernelGGL((mha_q_kernel<1, true>), dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16), 1, slices), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((mha_q_kernel<1, false>), dim3((unsigned)((p.nsplit * B * H + 15) / 16 * 16), 1, slices), dim3(256), 0, stream, p);
-    const size_t shm = (size_t)slices * MQ * 64 * 2 + 4 * KB * 64 + (size_t)slices * MQ * 8;
+    const size_t shm = (size_t)slices * MQ * 64 * 2 + 4 * KB * 64 + (size_t)slices * MQ * 8 + (mask != nullptr ? (size_t)KB * (slices * MQ + 4) : 0);
     if (shm > 160 * 1024) return UENC_EINVAL;
     const bool drop = p.drop_thresh != 0u;
     if (shm > 64 * 1024) {
