@@ -23,6 +23,10 @@
 #include "lds_frag.h"
 
 #define LOG2E 1.4426950408889634f
+// v_max without the canonicalising v_max x, x that fmaxf() carries for signalling NaNs (the scores are finite or -inf here)
+__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#define NEG_INF (-__builtin_huge_valf())
 #define MQ 160            // queries per launch slice (10 MFMA tiles)
 #define MQT 10
 #define KB 64             // keys per LDS block
@@ -184,32 +188,46 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                 for (int kt = 0; kt < 4; ++kt)
                     if (kbase + kt * 16 + 4 * fg < k_end) mk[kt] = *(const unsigned*)(mrow + kt * 16);
             }
-            float mloc = -1e30f;
-            bool ok[4][4];
+            // The softmax arithmetic was 12.5 VALU instructions per score (260 per query tile and block: scale, two compares and an AND for
+            // validity, select + canonicalising max, subtract, exp, select, add ...) and the kernels are issue-bound on it.  Now a blocked or
+            // out-of-range score is set to -inf ONCE (and not at all in a full, unmasked block), the running maximum is taken on the raw
+            // scores (the scale is positive), and exp2(fma(s, scale, -max)) needs no select: exp2(-inf) = 0.
+            const bool hasmask = p.mask != nullptr, fullblk = kbase + KB <= k_end;         // wave-uniform
+            float v[4][4];                              // (a copy in plain registers: the MFMA results live in accumulation registers)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kbase + kt * 16 + 4 * fg + r;
-                    ok[kt][r] = (key < k_end) && (((mk[kt] >> (8 * r)) & 0xffu) == 0u);
-                    s[kt][r] *= sc;
-                    if (ok[kt][r]) mloc = fmaxf(mloc, s[kt][r]);
-                }
+                for (int r = 0; r < 4; ++r) v[kt][r] = s[kt][r];
+            if (hasmask || !fullblk) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kbase + kt * 16 + 4 * fg + r;
+                        const bool okk = (key < k_end) && (((mk[kt] >> (8 * r)) & 0xffu) == 0u);
+                        v[kt][r] = okk ? v[kt][r] : NEG_INF;
+                    }
+            }
             if (MODE == 0) {
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                const float mnew = fmaxf(m_run[i], mloc);
+                float mloc = vmax3f(v[0][0], v[0][1], v[0][2]);
+                mloc = vmax3f(mloc, v[0][3], v[1][0]); mloc = vmax3f(mloc, v[1][1], v[1][2]); mloc = vmax3f(mloc, v[1][3], v[2][0]);
+                mloc = vmax3f(mloc, v[2][1], v[2][2]); mloc = vmax3f(mloc, v[2][3], v[3][0]); mloc = vmax3f(mloc, v[3][1], v[3][2]);
+                mloc = vmaxf(mloc, v[3][3]);
+                mloc = vmaxf(mloc, __shfl_xor(mloc, 16));
+                mloc = vmaxf(mloc, __shfl_xor(mloc, 32));
+                const float mnew = vmaxf(m_run[i], mloc * sc);        // (-inf * sc = -inf: a block with nothing visible keeps the running maximum)
                 const float alpha = fast_exp2(m_run[i] - mnew);
+                const float nm = -mnew;
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = ok[kt][r] ? fast_exp2(s[kt][r] - mnew) : 0.f;
+                        const float e = fast_exp2(__builtin_fmaf(v[kt][r], sc, nm));
                         sum += e;                                    // the softmax normaliser is taken BEFORE dropout
-                        s[kt][r] = e;
+                        v[kt][r] = e;
                         if (DROP)
-                            s[kt][r] = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
+                            v[kt][r] = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
                                            ? e * p.inv_keep : 0.f;
                     }
                 sum += __shfl_xor(sum, 16);
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                 for (int kb2 = 0; kb2 < 2; ++kb2) {
                     bf16x8 pb;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pb[r] = (bf16)s[2 * kb2][r]; pb[4 + r] = (bf16)s[2 * kb2 + 1][r]; }
+                    for (int r = 0; r < 4; ++r) { pb[r] = (bf16)v[2 * kb2][r]; pb[4 + r] = (bf16)v[2 * kb2 + 1][r]; }
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
                         o[i][dt] = mfma16(frag_tr(Vc, 32 * kb2, 32 * kb2 + 16, dt * 16, lane), pb, o[i][dt]);
@@ -236,19 +254,19 @@ __global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
                     const f32x4 dp = mfma16(frag_rows(Vc, kt * 16, fr, fg), dof[i], zero4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pr = ok[kt][r] ? fast_exp2(s[kt][r] - lse_q[i]) : 0.f;
+                        const float pr = fast_exp2(__builtin_fmaf(v[kt][r], sc, -lse_q[i]));
                         float dpv = dp[r];
                         if (DROP)
                             dpv = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
                                       ? dpv * p.inv_keep : 0.f;
-                        s[kt][r] = pr * (dpv - dl_q[i]);
+                        v[kt][r] = pr * (dpv - dl_q[i]);
                     }
                 }
 #pragma unroll
                 for (int kb2 = 0; kb2 < 2; ++kb2) {
                     bf16x8 pb;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pb[r] = (bf16)s[2 * kb2][r]; pb[4 + r] = (bf16)s[2 * kb2 + 1][r]; }
+                    for (int r = 0; r < 4; ++r) { pb[r] = (bf16)v[2 * kb2][r]; pb[4 + r] = (bf16)v[2 * kb2 + 1][r]; }
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
                         o[i][dt] = mfma16(frag_tr(Kc, 32 * kb2, 32 * kb2 + 16, dt * 16, lane), pb, o[i][dt]);
@@ -433,10 +451,13 @@ __global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qt * 16 + 4 * fg + r;
-                    bool ok = (key < k_end) && (qi < p.Lq);
-                    if (masked) ok = ok && ((mw >> (8 * r)) & 0xffu) == 0u;
-                    const float pr = ok ? fast_exp2(sv[r] * sc - lv[r]) : 0.f;
+                    // (no validity tests: a padding query has zero Q / dO rows, lse = delta = 0 -> adds nothing; a key past the end only
+                    // feeds its own column, which is never stored; a blocked score becomes -inf -> p = 0)
+                    float svr = sv[r];
+                    if (masked) svr = (((mw >> (8 * r)) & 0xffu) == 0u) ? svr : NEG_INF;
+                    const float pr = fast_exp2(__builtin_fmaf(svr, sc, -lv[r]));
                     float keepw = 1.0f;
+                    const bool ok = DROP && (key < k_end) && (qi < p.Lq) && pr != 0.f;
                     if (DROP && ok)
                         keepw = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qi) * p.S + key) ? p.inv_keep : 0.f;
                     pt[h2][r] = pr * keepw;
