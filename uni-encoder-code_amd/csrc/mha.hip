@@ -83,7 +83,7 @@ __device__ __forceinline__ bool mha_decode_block(const MhaP& p, int& split, int&
 // forward (MODE 0) and dQ (MODE 1): waves own query tiles, loop over the key range
 // ------------------------------------------------------------------------------------------------
 template <int MODE, bool DROP>
-__global__ __launch_bounds__(256) void mha_q_kernel(MhaP p) {
+__global__ __launch_bounds__(256, 2) void mha_q_kernel(MhaP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(MQ + MQ + 4 * KB) * 64];
     unsigned char* Qs = smem;
     unsigned char* dOs = smem + MQ * 64;                 // dQ mode only
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void mha_combine_kernel(MhaP p, int nslices) {
 // dK / dV: a wave owns a 16-key tile of each 64-key block and sweeps all queries
 // ------------------------------------------------------------------------------------------------
 template <bool DROP>
-__global__ __launch_bounds__(256) void mha_dkdv_kernel(MhaP p) {
+__global__ __launch_bounds__(256, 2) void mha_dkdv_kernel(MhaP p) {
     constexpr int NQB = MQT / 2;     // 32-query blocks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nslices = (p.Lq + MQ - 1) / MQ;
