@@ -314,6 +314,10 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
             self._mem_cache.clear()
             mem = self.pe_layer.tokens(B, H4, W4, dev).contiguous()
             self._mem_cache[mkey] = mem
+            if not K.EXACT:
+                # its bf16 operand copy lives as long as the map itself (a twin registered for the per-call reshaped view died with that
+                # view after every backward, and the 268 MB map was re-cast every step)
+                ops._register_twin(mem, K.cast_bf16(mem.view(-1, mem.shape[-1])))
         # (bf16 result: the sum only feeds the two key projections of the class transformer)
         key_in = ops.linear(mf32, self.class_input_proj.weight, self.class_input_proj.bias, residual=mem, out_dtype=K.adt())
         tgt = t_tok.expand(-1, Q - 1, -1) if self.use_task_norm else torch.zeros_like(qe[:, :-1])
@@ -321,7 +325,9 @@ class ContrastiveMultiScaleMaskedTransformerDecoder(nn.Module):
         output = torch.cat([out_t, t_tok], 1)
         query_class = output                                 # reference :440, 477-478: the PRE-loop queries (batch-first here)
 
-        mf16 = mf32.detach().to(K.adt())
+        mf16 = None if K.EXACT else ops._twin(mf32)          # the bf16 copy the class_input_proj GEMM above made of the same map
+        if mf16 is None:
+            mf16 = mf32.detach().to(K.adt())
         # (B, C, HW) bf16 operand of the mask-embedding gradient GEMM: LDS-tiled cast + transpose per image (a strided ATen copy of the
         # 134 MB map took 0.28 ms)
         mf16_chw = torch.empty((B, mf32.shape[2], mf32.shape[1]), dtype=K.adt(), device=mf32.device)
