@@ -26,3 +26,5 @@ timeout -k 10 300 python tools/gemm_time_by_shape.py > $R/r03_gemm_shapes.txt 2>
 cp $R/r03_pmc_traffic.json $R/r03_mfma_util.json profiles/
 timeout -k 10 400 python bench.py --steps 8 --no-cpu-baseline --no-extras > $R/r03_bench_quoting_pmc.json 2>/dev/null || exit 1
 echo DONE
+UENC_BENCH_BACKBONE=dinat timeout -k 10 400 python bench.py --steps 6 --warmup 3 --no-extras --no-cpu-baseline > $R/r03_bench_dinat.json 2>/dev/null || exit 1
+echo DONE2

@@ -1,0 +1,32 @@
+"""ATen operators of one bench step with input shapes and device time (torch.profiler), to find glue that should live in a HIP kernel."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uni-encoder-code_amd"))
+import bench as T
+from uenc import ops
+from uenc.d2 import build_model
+from uenc.dp import GradBuckets
+from torch.profiler import profile, ProfilerActivity
+torch.manual_seed(0)
+model = build_model(T.make_cfg("cuda")); model.eval()
+buckets = GradBuckets(model)
+g = torch.Generator().manual_seed(1000)
+batch = [{"left_image": torch.randint(0, 256, (3, T.H_IMG, T.W_IMG), generator=g).float().cuda(), "task": "The task is panoptic", "type": "segmentation",
+          "height": T.H_IMG, "width": T.W_IMG} for _ in range(T.PER_GPU_BATCH)]
+def step():
+    buckets.zero_grad(); ops.begin_step(fresh_grads=True)
+    out, images = model.forward_features(batch)
+    with torch.no_grad(): model.upsample_masks(out["pred_masks"], images.tensor.shape[-2:])
+    T.synthetic_loss(out).backward(); buckets.finish()
+for _ in range(3): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    step(); torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=4) if e.key.startswith("aten::") and (getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)) > 0]
+tm = lambda e: getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
+rows.sort(key=lambda e: -tm(e))
+tot = sum(tm(e) for e in rows)
+print(f"aten ops with device time: {tot / 1e3:.2f} ms")
+for e in rows[:45]:
+    st = [s for s in (e.stack or []) if "uenc" in s or "bench" in s][:2]
+    print(f"{tm(e) / 1e3:7.3f} ms {e.count:4d} x {e.key:28s} {str(e.input_shapes)[:70]:70s} {' | '.join(s.split('/')[-1][:60] for s in st)}")
