@@ -242,7 +242,7 @@ def test_full_model_with_dinat_backbone(U):
     wl.backward()
     record_parity("dinat_unpinned/small_full_model_free_running", pinned_by="oracle/dinat_ref.py + oracle/torch_ref.py (backbone unpinned)",
                   pred_logits=rel(out["pred_logits"], want["pred_logits"]), pred_masks=rel(out["pred_masks"], want["pred_masks"]),
-                  loss=float(loss), loss_oracle=float(wl), mask_band=mask_band_figures(out["pred_masks"], want["pred_masks"]))
+                  loss=float(loss.detach()), loss_oracle=float(wl.detach() if hasattr(wl, "detach") else wl), mask_band=mask_band_figures(out["pred_masks"], want["pred_masks"]))
     assert rel(out["pred_logits"], want["pred_logits"]) < 0.15 and rel(out["pred_masks"], want["pred_masks"]) < 0.15
     assert abs(float(loss) / float(wl) - 1) < 0.1
     cos = []
