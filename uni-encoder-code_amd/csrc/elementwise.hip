@@ -123,6 +123,36 @@ __global__ __launch_bounds__(1024) void attn_mask_kernel(const float* __restrict
     uint8_t* dst = out + (long)blockIdx.x * Ho * Wo;
     const int wq = Wo / VEC, total = Ho * wq;
     int open_any = 0;
+    // Exact 2x / 4x reductions (the 1/8 and 1/16 key maps of a 1/4-resolution mask): the two taps of an output pixel are the source pixels
+    // s x + s/2 - 1 and s x + s/2 with weights 1/2, so the 4 outputs of a thread read 8 (16) CONSECUTIVE floats of two source rows: two
+    // (four) 16-byte loads per row, all in flight before the first use, instead of 16 dependent 4-byte loads per iteration.  The
+    // arithmetic is the generic expression with hx = lx = hy = ly = 1/2, term for term (same bits).
+    if (VEC == 4 && (Wi & 3) == 0 && ((Hi == 2 * Ho && Wi == 2 * Wo) || (Hi == 4 * Ho && Wi == 4 * Wo)) && (((uintptr_t)src) & 15) == 0) {
+        const int S = Hi / Ho;
+        for (int idx = threadIdx.x; idx < total; idx += 1024) {
+            const int oy = idx / wq, xq = idx - oy * wq;
+            const int y0 = S * oy + S / 2 - 1;
+            const float4* r0 = (const float4*)(src + (long)y0 * Wi + (long)xq * 4 * S);
+            const float4* r1 = (const float4*)(src + (long)(y0 + 1) * Wi + (long)xq * 4 * S);
+            float a0[4], a1[4], b0[4], b1[4];        // taps x0 / x1 of rows y0 / y1 for the 4 outputs
+            if (S == 2) {
+                const float4 p0 = r0[0], p1 = r0[1], q0 = r1[0], q1 = r1[1];
+                a0[0] = p0.x; a1[0] = p0.y; a0[1] = p0.z; a1[1] = p0.w; a0[2] = p1.x; a1[2] = p1.y; a0[3] = p1.z; a1[3] = p1.w;
+                b0[0] = q0.x; b1[0] = q0.y; b0[1] = q0.z; b1[1] = q0.w; b0[2] = q1.x; b1[2] = q1.y; b0[3] = q1.z; b1[3] = q1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float4 pv = r0[j], qv = r1[j]; a0[j] = pv.y; a1[j] = pv.z; b0[j] = qv.y; b1[j] = qv.z; }
+            }
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = 0.5f * (0.5f * a0[j] + 0.5f * a1[j]) + 0.5f * (0.5f * b0[j] + 0.5f * b1[j]);
+                packed |= (v < 0.f ? 1u : 0u) << (8 * j);
+            }
+            open_any |= packed != 0x01010101u;
+            *(uint32_t*)(dst + (long)oy * Wo + xq * 4) = packed;
+        }
+    } else
     for (int idx = threadIdx.x; idx < total; idx += 1024) {
         const int oy = idx / wq, xq = idx - oy * wq;
         float fy = ((float)oy + 0.5f) * sy - 0.5f;
