@@ -131,6 +131,14 @@ int uenc_gemm_nt(const void* A, int a_dtype, long lda, const void* W, long ldw, 
 int uenc_gemm_nt_scaled(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                         int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                         void* aux_out, long ldaux_out, float alpha, const float* sample_scale, int rows_per_sample, uenc_stream_t stream);
+/* Linear -> residual add -> LayerNorm with the LayerNorm inside the GEMM's epilogue (pixel_decoder/msdeformattn.py:111-142 at d_model 256,
+ * backbone/swin.py:262-295 at C = 192): C (M, N) fp32, ldc == N, receives the pre-norm sum h = A W^T + bias + residual (the LayerNorm
+ * backward reads it), y32 / y16 (either may be NULL) the normalised rows as fp32 / bf16, stats (M, 2) = (mean, rstd) (may be NULL).
+ * The row must fit one column tile of an LDS-staged kernel: N <= 256, N % 8 == 0, bf16 A, K % 64 == 0, M large enough for the tiled kernels;
+ * returns -1 (nothing launched) otherwise: run uenc_gemm_nt + uenc_layernorm_fwd then (same numbers up to fp32 summation order). */
+int uenc_gemm_nt_ln(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                    const void* residual, long ldres, const float* gamma, const float* beta, float eps, float* y32, void* y16, float* stats,
+                    uenc_stream_t stream);
 /* Split-K with STORED partial sums (no atomics): split s of `splitk` writes its fp32 partial product to P + s * part_stride
  * (row stride ldp); the caller sums the slices.  splitk must equal uenc_gemm_nt_splits(K, requested) (the number of non-empty
  * k-ranges after rounding to 64).  Replaces the reference's torch.einsum("bqc,bchw->bqhw") backward w.r.t. the mask embedding

@@ -625,3 +625,26 @@ def test_msdeform_fused_bwd_tiled_equals_one_kernel(K, shapes_l, spread, tile, m
         den = float(d0.float().abs().max())
         assert float((d1.float() - d0.float()).abs().max()) <= 2 ** -7 * den
         assert float((d1.float() - d0.float()).norm() / d0.float().norm()) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K_", [(20000, 256, 256), (86016, 256, 1024), (50000, 192, 192), (70001, 256, 2048), (33000, 200, 320)])
+def test_gemm_nt_ln_fused_epilogue(K, M, N, K_):
+    """Linear -> residual add -> LayerNorm with the LayerNorm inside the GEMM epilogue (uenc_gemm_nt_ln) against uenc_gemm_nt +
+    uenc_layernorm_fwd on the same operands: the half-height kernel (N = 256, K <= 1024), the 256 x 192 and 256 x 256 tiles of the persistent
+    kernel, ragged M and an N that is not a multiple of 16; pre-norm sum, fp32 / bf16 normalised rows and (mean, rstd)."""
+    a = _r(M, K_, seed=1, dtype=torch.bfloat16)
+    w = _r(N, K_, seed=2, scale=K_ ** -0.5, dtype=torch.bfloat16)
+    bias, res = _r(N, seed=3), _r(M, N, seed=4)
+    gamma, beta = 1.0 + 0.3 * _r(N, seed=5), 0.2 * _r(N, seed=6)
+    fz = K.gemm_nt_ln(a, w, bias, res, gamma, beta, eps=1e-5)
+    assert fz is not None, "shape should take a fused kernel"
+    h, y32, y16, st = fz
+    h0 = K.gemm_nt(a, w, bias=bias, epilogue=K.EPI_RESIDUAL, aux=res, out_dtype=torch.float32)
+    tw = []
+    y0, _, st0 = K.layernorm_fwd(h0, gamma, beta, out_dtype=torch.float32, twin=tw, eps=1e-5)
+    assert torch.equal(h, h0)                                   # the same GEMM arithmetic
+    _close(y32, y0, 2e-5, 2e-5)
+    _close(st, st0, 1e-5 * float(st0.abs().max()), 2e-5)
+    assert float((y16.float() - tw[0].float()).abs().max()) <= 2 ** -7 * float(y0.abs().max())
+    # shapes the fused kernels do not take are refused, nothing written
+    assert K.gemm_nt_ln(a[:300], w, bias, res[:300], gamma, beta) is None

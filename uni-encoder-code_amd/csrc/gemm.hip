@@ -45,6 +45,10 @@ struct GemmNT {
     long part_stride;     // > 0: split-K with STORED partials: split y writes its tile to C + y * part_stride (fp32 elements), no atomics
     int splits;           // gridDim.y
     long bsA, bsW, bsC;   // batched form (gemm_nt_kernel only): element strides between the problems of blockIdx.z
+    // LayerNorm fused into the fp32 residual epilogue of the LDS-staged kernels when ONE column tile covers the row (N <= 256): the 32
+    // threads that share a row of the staged tile reduce it, and y = LN(C row) leaves as fp32 and / or bf16 beside C (the pre-norm sum the
+    // LayerNorm backward needs) and the row's (mean, rstd).  ln_gamma == nullptr: off.
+    const float* ln_gamma; const float* ln_beta; float* ln_y32; bf16* ln_y16; float2* ln_stats; float ln_eps;
 };
 
 // alpha of output row m: p.alpha, times the row's sample scale when one is given (DropPath: 0 or 1 / keep_prob per image)
@@ -594,7 +598,7 @@ __device__ __forceinline__ void nt_epilogue_direct(const GemmNT& p, f32x4 (&acc)
 // ---- LDS-staged epilogue (fp32 results; bf16 under UENC_GEMM_VARIANT bit 32768): passes of 64 rows through a padded fp32 tile [64][260]
 // in LDS, then 8 consecutive columns per thread: 1 KB runs per row.  NWM = row groups of 128 the workgroup owns (wave group wm each). ----
 // NI = column groups of 16 per wave (4, or 3 for the 192-wide tile: the tile then spans 4 x 48 columns and the threads of the last 64 idle).
-template <int EPI, int OUT_F32, int NTHREADS, int NWM, int NI = 4>
+template <int EPI, int OUT_F32, int NTHREADS, int NWM, int NI = 4, bool LN = false>
 __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)[4][8], unsigned char* smem, int m0, int n0, int wm, int wn,
                                                    int t, int fr, int fg, bool lead, bool skip_stores) {
     float* T = (float*)smem;
@@ -602,10 +606,18 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
     const int erow = t >> 5, ecol = (t & 31) * 8;
     constexpr int RPI = NTHREADS / 32;            // rows one iteration of the workgroup covers
     constexpr int NIT = 64 / RPI;
-    const bool hoist = !(p.variant & 1048576);
+    const bool hoist = !(p.variant & 1048576) && !LN;       // (the fused-LayerNorm form loads its residual row by row)
     const int n = n0 + ecol;
     const bool ncol_ok = n < p.N && ecol < NI * 64;
     const bool full8 = (n + 8 <= p.N);
+    constexpr bool ln = LN && EPI == EPI_RESIDUAL && OUT_F32;      // own instantiation (the launcher guarantees one column tile, N % 8 == 0)
+    float lgam[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lbet[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ln && ncol_ok) {
+        const float4 g0 = *(const float4*)(p.ln_gamma + n), g1 = *(const float4*)(p.ln_gamma + n + 4);
+        const float4 b0 = *(const float4*)(p.ln_beta + n), b1 = *(const float4*)(p.ln_beta + n + 4);
+        lgam[0] = g0.x; lgam[1] = g0.y; lgam[2] = g0.z; lgam[3] = g0.w; lgam[4] = g1.x; lgam[5] = g1.y; lgam[6] = g1.z; lgam[7] = g1.w;
+        lbet[0] = b0.x; lbet[1] = b0.y; lbet[2] = b0.z; lbet[3] = b0.w; lbet[4] = b1.x; lbet[5] = b1.y; lbet[6] = b1.z; lbet[7] = b1.w;
+    }
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr && ncol_ok && lead) {
         const float4 b0 = *(const float4*)(p.bias + n);
@@ -642,13 +654,58 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
             }
         }
         __syncthreads();
-        if (!ncol_ok) continue;
+        if (!ncol_ok && !ln) continue;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rl = it * RPI + erow;
             const int m = m0 + ps * 64 + rl;
             if (EPI == EPI_RESIDUAL && hoist && it == 4) fetch_res(4);
             if (m >= p.M) continue;
+            if (ln) {
+                // fused LayerNorm: the 32 lanes of this half-wave hold the row (lanes past N carry zeros and only take part in the sums)
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (ncol_ok) {
+                    const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
+                    const float al = nt_alpha(p, m);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = (a0[r] + bv[r]) * al; v[4 + r] = (a1[r] + bv[4 + r]) * al; }
+                    const float* rp = (const float*)p.aux + (long)m * p.ldaux + n;
+                    const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                    float* c = (float*)p.C + (long)m * p.ldc + n;
+                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                const float invn = 1.0f / (float)p.N;
+                float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) s1 += __shfl_xor(s1, o);
+                const float mean = s1 * invn;
+                float d[8], s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { d[r] = ncol_ok ? v[r] - mean : 0.f; s2 += d[r] * d[r]; }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) s2 += __shfl_xor(s2, o);
+                const float rstd = rsqrtf(s2 * invn + p.ln_eps);
+                if (ncol_ok) {
+                    float y[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) y[r] = d[r] * rstd * lgam[r] + lbet[r];
+                    if (p.ln_y32 != nullptr) {
+                        float* yp = p.ln_y32 + (long)m * p.N + n;
+                        *(float4*)yp = make_float4(y[0], y[1], y[2], y[3]);
+                        *(float4*)(yp + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                    }
+                    if (p.ln_y16 != nullptr) {
+                        bf16x8 o8;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o8[r] = (bf16)y[r];
+                        *(bf16x8*)(p.ln_y16 + (long)m * p.N + n) = o8;
+                    }
+                }
+                if (ecol == 0 && p.ln_stats != nullptr) p.ln_stats[m] = make_float2(mean, rstd);
+                continue;
+            }
             const f32x4 a0 = *(const f32x4*)(T + rl * LDT + ecol), a1 = *(const f32x4*)(T + rl * LDT + ecol + 4);
             float v[8];
             const float al = nt_alpha(p, m);
@@ -727,7 +784,7 @@ __device__ __forceinline__ void nt_epilogue_staged(const GemmNT& p, f32x4 (&acc)
 // alone (a 64-row, 8 KB half-tile: ONE DMA instruction per thread, and quadrants of 16 / 8 / 8 / 16 MFMAs).  For the shapes whose
 // 256-wide tiling leaves CUs idle or columns empty: N = 768 at M = 16384 is 192 tiles of 256 x 256 on 256 CUs but 256 tiles of
 // 256 x 192; N = 2304 is 2.25 rounds of tiles against 3 rounds of 3/4 the work; N = 384 / 576 / 192 waste a quarter of their last column.
-template <int EPI, int OUT_F32, int PIPE, int BNT = BN2>
+template <int EPI, int OUT_F32, int PIPE, int BNT = BN2, bool LN = false>
 __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
     static_assert(BNT == 256 || (BNT == 192 && PIPE == 1), "tile width");
     constexpr int NI = BNT / 64;          // column groups of 16 per wave
@@ -1067,7 +1124,7 @@ __global__ __launch_bounds__(T2) void gemm_nt256_kernel(GemmNT p) {
         pos = pos_next;
         continue;
     }
-    nt_epilogue_staged<EPI, OUT_F32, T2, 2, NI>(p, acc, smem, m0, n0, wm, wn, t, fr, fg, blockIdx.y == 0, (p.variant & 8192) != 0);
+    nt_epilogue_staged<EPI, OUT_F32, T2, 2, NI, LN>(p, acc, smem, m0, n0, wm, wn, t, fr, fg, blockIdx.y == 0, (p.variant & 8192) != 0);
     if (!has_next) return;
     __syncthreads();          // the staged epilogue's last reads of the LDS tile precede the next tile's DMA writes
     pos = pos_next;
@@ -1100,7 +1157,7 @@ __device__ __forceinline__ int lds_off32(int row, int chunk) {
     return row * 64 + ((chunk ^ f) << 4);
 }
 
-template <int EPI, int OUT_F32>
+template <int EPI, int OUT_F32, bool LN = false>
 __global__ __launch_bounds__(T3, 2) void gemm_nt128_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 3 x (A 8 KB + W 16 KB)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1167,20 +1224,20 @@ __global__ __launch_bounds__(T3, 2) void gemm_nt128_kernel(GemmNT p) {
         return;
     }
     __syncthreads();          // the staged epilogue reuses the ring
-    nt_epilogue_staged<EPI, OUT_F32, T3, 1>(p, acc, smem, m0, n0, 0, wn, t, fr, fg, true, false);
+    nt_epilogue_staged<EPI, OUT_F32, T3, 1, 4, LN>(p, acc, smem, m0, n0, 0, wn, t, fr, fg, true, false);
 }
 
-template <int EPI, int OUT_F32>
+template <int EPI, int OUT_F32, bool LN = false>
 static int launch_nt128(GemmNT& p, hipStream_t stream) {
     p.tiles_m = (p.M + BM3 - 1) / BM3; p.tiles_n = (p.N + BN3 - 1) / BN3;
     static bool attr_set = false;      // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt128_kernel<EPI, OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt128_kernel<EPI, OUT_F32, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     p.persist = 0;
-    hipLaunchKernelGGL((gemm_nt128_kernel<EPI, OUT_F32>), dim3(p.tiles_m * p.tiles_n), dim3(T3), 3 * STAGE3, stream, p);
+    hipLaunchKernelGGL((gemm_nt128_kernel<EPI, OUT_F32, LN>), dim3(p.tiles_m * p.tiles_n), dim3(T3), 3 * STAGE3, stream, p);
     return UENC_OK;
 }
 
@@ -1194,12 +1251,12 @@ static int nt_cu_count() {
     return ncu;
 }
 
-template <int EPI, int OUT_F32, int PIPE, int BNT = BN2>
+template <int EPI, int OUT_F32, int PIPE, int BNT = BN2, bool LN = false>
 static int launch_nt256(GemmNT& p, hipStream_t stream) {
     p.tiles_m = (p.M + BM2 - 1) / BM2; p.tiles_n = (p.N + BNT - 1) / BNT;
     static bool attr_set = false;      // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32, PIPE, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, OUT_F32, PIPE, BNT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -1207,7 +1264,7 @@ static int launch_nt256(GemmNT& p, hipStream_t stream) {
     const int ncu = nt_cu_count();
     const int ntiles = p.tiles_m * p.tiles_n;
     p.persist = (PIPE == 1 && p.splits == 1 && ntiles > ncu && !(p.variant & 65536)) ? 1 : 0;
-    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE, BNT>), dim3(p.persist ? ncu : ntiles, p.splits), dim3(T2), 131072, stream, p);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, OUT_F32, PIPE, BNT, LN>), dim3(p.persist ? ncu : ntiles, p.splits), dim3(T2), 131072, stream, p);
     return UENC_OK;
 }
 
@@ -1239,10 +1296,13 @@ static bool nt128_wins(int M, int N, int K, int epilogue, int c_dtype, int varia
     return N > 192 && N <= 288 && K <= 1024;
 }
 
+struct NtLn { const float* gamma; const float* beta; float* y32; void* y16; float* stats; float eps; };
+
 static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, int c_dtype, long ldc,
                         int M, int N, int K, const float* bias, int epilogue, const void* aux, long ldaux,
                         void* aux_out, long ldaux_out, float alpha, int splitk, int accumulate, int batch, long bsA, long bsW,
-                        long bsC, hipStream_t stream, long part_stride = 0, const float* sample_scale = nullptr, int rows_per_sample = 0) {
+                        long bsC, hipStream_t stream, long part_stride = 0, const float* sample_scale = nullptr, int rows_per_sample = 0,
+                        const NtLn* ln = nullptr) {
     UENC_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0);
     UENC_CHECK_ARG(a_dtype == UENC_F32 || a_dtype == UENC_BF16);
     UENC_CHECK_ARG(c_dtype == UENC_F32 || c_dtype == UENC_BF16);
@@ -1279,6 +1339,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         p.sample_scale = sample_scale; p.inv_rows = 1.0f / (float)rows_per_sample;
     }
     p.bsA = bsA; p.bsW = bsW; p.bsC = bsC;
+    p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_y32 = nullptr; p.ln_y16 = nullptr; p.ln_stats = nullptr; p.ln_eps = 0.f;
     dim3 grid(p.tiles_m * p.tiles_n, splitk, batch), block(GEMM_THREADS);
     const bool prof = uenc_prof_on();
     // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
@@ -1305,6 +1366,7 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
         if (aux_out != nullptr) bytes += mn * 2;
         uenc_prof_begin(half_tile ? UENC_PROF_GEMM_NT128 : big ? UENC_PROF_GEMM_NT256 : UENC_PROF_GEMM_NT, 2.0 * batch * M * (double)N * K, stream, batch * bytes);
     }
+    if (ln != nullptr && !(big || mid)) return UENC_EINVAL;       // (the small-shape kernels have no row-wide epilogue: the caller runs LayerNorm itself)
     // few output tiles (the decoder's M = 300-row GEMMs): the K-split 64 x 64 kernel
     const long tiles128 = (long)p.tiles_m * p.tiles_n;
     if (!big && batch == 1 && !p.atomic && !partials && tiles128 <= 32 && K >= 64 && !(p.variant & 1024)) {
@@ -1339,9 +1401,20 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     }
     if (big || mid) {
         int rc = UENC_EINVAL;
-        const bool narrow = big && !half_tile && !p.atomic && !partials && nt192_wins(M, N, p.variant);
+        bool narrow = big && !half_tile && !p.atomic && !partials && nt192_wins(M, N, p.variant);
+        if (ln != nullptr) {
+            // fused LayerNorm: the row must sit in ONE column tile of an LDS-staged fp32 epilogue
+            UENC_CHECK_ARG(epilogue == EPI_RESIDUAL && c_dtype == UENC_F32 && !p.atomic && !partials && N <= 256 && N % 8 == 0 && ldc == N &&
+                           ln->gamma && ln->beta && (ln->y32 || ln->y16) && !(p.variant & 8192));
+            UENC_CHECK_ARG((((uintptr_t)ln->gamma | (uintptr_t)ln->beta | (uintptr_t)ln->y32 | (uintptr_t)ln->y16) & 15) == 0 && ((uintptr_t)ln->stats & 7) == 0);
+            narrow = narrow && N <= 192;
+            p.ln_gamma = ln->gamma; p.ln_beta = ln->beta; p.ln_y32 = ln->y32; p.ln_y16 = (bf16*)ln->y16; p.ln_stats = (float2*)ln->stats; p.ln_eps = ln->eps;
+        }
 #define LAUNCH2(E, F) rc = half_tile ? launch_nt128<E, F>(p, stream) : (p.variant & 128) ? launch_nt256<E, F, 0>(p, stream) : narrow ? launch_nt256<E, F, 1, 192>(p, stream) : launch_nt256<E, F, 1>(p, stream)   /* bit 128: the two-stage loop, for A/B */
-        if (c_dtype == UENC_F32) {
+        if (ln != nullptr) {          // (checked above: fp32 residual epilogue, one column tile)
+            rc = half_tile ? launch_nt128<EPI_RESIDUAL, 1, true>(p, stream)
+                           : narrow ? launch_nt256<EPI_RESIDUAL, 1, 1, 192, true>(p, stream) : launch_nt256<EPI_RESIDUAL, 1, 1, BN2, true>(p, stream);
+        } else if (c_dtype == UENC_F32) {
             if (epilogue == EPI_NONE) LAUNCH2(EPI_NONE, 1);
             else if (epilogue == EPI_RESIDUAL) LAUNCH2(EPI_RESIDUAL, 1);
             else if (epilogue == EPI_RELU) LAUNCH2(EPI_RELU, 1);
@@ -1399,6 +1472,20 @@ extern "C" int uenc_gemm_nt_scaled(const void* A, int a_dtype, long lda, const v
     UENC_CHECK_ARG(sample_scale != nullptr && rows_per_sample > 0);
     return gemm_nt_impl(A, a_dtype, lda, W, ldw, C, c_dtype, ldc, M, N, K, bias, epilogue, aux, ldaux, aux_out, ldaux_out, alpha, 1,
                         0, 1, 0, 0, 0, stream, 0, sample_scale, rows_per_sample);
+}
+
+// y = LayerNorm(A W^T + bias + residual) with the LayerNorm inside the GEMM's epilogue (reference: Linear -> residual add -> nn.LayerNorm, e.g.
+// pixel_decoder/msdeformattn.py:111-142, backbone/swin.py:262-295 at C = 192): C receives the pre-norm sum h (fp32, ldc == N; the LayerNorm
+// backward reads it), y32 / y16 (either may be NULL) the normalised row as fp32 / bf16, stats (M, 2) = (mean, rstd) per row (may be NULL).
+// Needs N <= 256, N % 8 == 0, bf16 A and a shape the LDS-staged kernels take; returns -1 (nothing launched) otherwise -- run
+// uenc_gemm_nt + uenc_layernorm_fwd then.
+extern "C" int uenc_gemm_nt_ln(const void* A, int a_dtype, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                               const void* residual, long ldres, const float* gamma, const float* beta, float eps, float* y32, void* y16, float* stats,
+                               hipStream_t stream) {
+    UENC_CHECK_ARG(residual != nullptr);
+    NtLn ln = {gamma, beta, y32, y16, stats, eps};
+    return gemm_nt_impl(A, a_dtype, lda, W, ldw, C, UENC_F32, ldc, M, N, K, bias, EPI_RESIDUAL, residual, ldres, nullptr, 0, 1.0f, 1, 0, 1, 0, 0, 0, stream, 0,
+                        nullptr, 0, &ln);
 }
 
 // Split-K with stored partial sums: split s (of `splitk`) writes sum over its k-range to P + s * part_stride (fp32, ldp); the

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "uenc_attn_mask": [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "uenc_gemm_nt": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_i, c_i, c_p],
     "uenc_gemm_nt_scaled": [c_p, c_i, c_l, c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_f, c_p, c_i, c_p],
+    "uenc_gemm_nt_ln": [c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
     "uenc_groupnorm_tokens_scratch_bytes": [c_i, c_i, c_i, c_i],
     "uenc_groupnorm_tokens_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "uenc_groupnorm_tokens_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

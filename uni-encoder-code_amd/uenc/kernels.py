@@ -206,6 +206,29 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[to
                            ptr(db), M, N, K, int(splitm), stream_ptr()), "gemm_tn")
 
 
+def gemm_nt_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+               eps: float = 1e-5, want_y32: bool = True, want_y16: bool = True):
+    """LayerNorm(a @ w^T + bias + residual) with the LayerNorm inside the GEMM's epilogue (one pass over the row instead of GEMM -> h ->
+    LayerNorm kernel).  a (M, K) bf16, w (N, K) bf16, residual (M, N) fp32, N <= 256.
+    -> (h fp32 pre-norm sum, y fp32 | None, y16 bf16 | None, stats (M, 2)) or None when the shape is not one the fused kernels take (the
+    caller then runs gemm_nt + layernorm_fwd); never in the fp32 verification mode."""
+    M, Kd = a.shape
+    N = w.shape[0]
+    if (EXACT or a.dtype != torch.bfloat16 or N > 256 or N % 8 or Kd % 64 or os.environ.get("UENC_GEMM_LN", "1") == "0"
+            or not (a.stride(1) == 1 and w.stride(1) == 1 and residual.is_contiguous() and residual.dtype == torch.float32)):
+        return None
+    h = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    y32 = torch.empty((M, N), dtype=torch.float32, device=a.device) if want_y32 else None
+    y16 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if want_y16 else None
+    stats = torch.empty((M, 2), dtype=torch.float32, device=a.device)
+    rc = lib.uenc_gemm_nt_ln(a.data_ptr(), dt(a), a.stride(0), w.data_ptr(), w.stride(0), h.data_ptr(), N, M, N, Kd, ptr(bias), residual.data_ptr(), N,
+                             gamma.data_ptr(), beta.data_ptr(), float(eps), ptr(y32), ptr(y16), stats.data_ptr(), stream_ptr())
+    if rc == -1:
+        return None
+    check(rc, "gemm_nt_ln")
+    return h, y32, y16, stats
+
+
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, res: Optional[torch.Tensor] = None,
                   out_dtype=torch.bfloat16, want_h: bool = False, want_stats: bool = True, eps: float = 1e-5,
                   twin: Optional[list] = None):

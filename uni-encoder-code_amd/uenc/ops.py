@@ -936,14 +936,24 @@ class DeformEncoderLayerFn(torch.autograd.Function):
                 loc, aw = offaw, ref
         if drop is None or K.EXACT:
             assert drop is None, "the fp32 verification mode has no dropout path"
-            h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
-            tw = []
-            s1, _, st1 = K.layernorm_fwd(h1, g1.detach(), b1.detach(), out_dtype=F32, twin=tw)
-            s1_16 = tw[0]
+            # both post-norms ride in the epilogue of the residual GEMM in front of them (d_model fits one column tile): no LayerNorm pass
+            fz = K.gemm_nt_ln(att, CACHE.mat(wo), bo.detach(), x, g1.detach(), b1.detach())
+            if fz is not None:
+                h1, s1, s1_16, st1 = fz
+            else:
+                h1 = K.gemm_nt(att, CACHE.mat(wo), bias=bo.detach(), epilogue=K.EPI_RESIDUAL, aux=x, out_dtype=F32)
+                tw = []
+                s1, _, st1 = K.layernorm_fwd(h1, g1.detach(), b1.detach(), out_dtype=F32, twin=tw)
+                s1_16 = tw[0]
             f = K.gemm_nt(s1_16, CACHE.mat(w1), bias=bb1.detach(), epilogue=K.EPI_RELU)                # (M, ffn) bf16
-            h2 = K.gemm_nt(f, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=s1, out_dtype=F32)
-            tw = []
-            out, _, st2 = K.layernorm_fwd(h2, g2.detach(), b2.detach(), out_dtype=F32, twin=tw)
+            fz = K.gemm_nt_ln(f, CACHE.mat(w2), bb2.detach(), s1, g2.detach(), b2.detach())
+            if fz is not None:
+                h2, out, o16, st2 = fz
+                tw = [o16]
+            else:
+                h2 = K.gemm_nt(f, CACHE.mat(w2), bias=bb2.detach(), epilogue=K.EPI_RESIDUAL, aux=s1, out_dtype=F32)
+                tw = []
+                out, _, st2 = K.layernorm_fwd(h2, g2.detach(), b2.detach(), out_dtype=F32, twin=tw)
         else:
             # training: dropout1 / 2 / 3 of the reference layer (:111-142) between the same kernels.  The branch outputs leave their GEMMs
             # as bf16, are masked in place (index-hash keep mask: nothing stored), and the residual sums move into the LayerNorm kernels.
