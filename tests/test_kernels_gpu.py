@@ -290,7 +290,7 @@ def test_gemm_tn_f32_dy(K):
     _close(dw, dy.to(torch.bfloat16).float().t() @ x.to(torch.bfloat16).float(), 5e-2, 2e-3)
 
 
-@pytest.mark.parametrize("M,N,K_", [(4096, 2560, 128), (5000, 2312, 192), (16384, 768, 768), (3000, 3584, 64 * 5), (41000, 192, 192)])
+@pytest.mark.parametrize("M,N,K_", [(4096, 2560, 128), (5000, 2312, 192), (16384, 768, 768), (3000, 3584, 64 * 5), (41000, 192, 192), (40008, 256, 288)])
 def test_gemm_nt_large_tile_path(K, M, N, K_):
     """Shapes that take the 256x256 LDS-DMA kernel (bf16 A, K % 64 == 0, >= 160 tiles), incl. ragged M / N and epilogues."""
     a = _r(M, K_, seed=1, dtype=torch.bfloat16)

@@ -1345,7 +1345,11 @@ static int gemm_nt_impl(const void* A, int a_dtype, long lda, const void* W, lon
     // large-tile path: bf16 A, K a multiple of 64, no split-K, enough 256x256 tiles to fill most CUs
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const int nmin = (p.variant & 64) ? 256 : 192;      // a 192-wide output still wins on the 256 tile: A is streamed once, not twice
-    const bool big = batch == 1 && a_dtype == UENC_BF16 && (K % BK == 0) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
+    // (a contraction that is a multiple of 32 but not of 64 -- the 288 columns of the deformable encoder's offset / weight projection -- fits the
+    // half-height kernel's 32-wide k-steps: it goes there when that kernel is the choice anyway, instead of to the register-staged one)
+    const bool k32 = (K % BK != 0) && (K % BK3 == 0) && !p.atomic && !partials && !(p.variant & 33554432) &&
+                     nt128_wins(M, N, K, epilogue, c_dtype, p.variant);
+    const bool big = batch == 1 && a_dtype == UENC_BF16 && ((K % BK == 0) || k32) && K >= 128 && lda % 8 == 0 && !(p.variant & 2) && N >= nmin && N % 8 == 0 &&
                      ((p.atomic || partials) ? (epilogue == EPI_NONE && c_dtype == UENC_F32 && p.klen % BK == 0 && tiles256 >= 4 && tiles256 * splitk >= 64 &&
                                   !(p.variant & 16))     // (a single skinny tile measured faster on the 128x128 kernel)
                                : tiles256 >= 160);
