@@ -59,7 +59,8 @@ int uenc_cast_transpose_f32_bf16(const float* src /* [R][C] */, void* dst /* [C]
 
 /* batched cast: `table` = n device-resident descriptors {const float* src; bf16* dst; int rows, cols, transpose, tiles_c;
  * long tile_begin;} (40 bytes each; tiles_c = ceil(cols / 64), tile_begin = exclusive prefix sum of 64x64 tile counts);
- * dst is [rows][cols] or, if transpose, [cols][rows].  One launch refreshes every bf16 weight operand of a model. */
+ * dst is [rows][cols] or, if (transpose & 1), [cols][rows]; transpose >> 4, when non-zero, is the leading dimension of dst in elements
+ * (several sources filling row / column blocks of one destination).  One launch refreshes every bf16 weight operand of a model. */
 int uenc_cast_multi(const void* table, int n, long total_tiles, uenc_stream_t stream);
 
 /* bilinear resize, align_corners = False, of NC fp32 planes (Hi, Wi) -> (Ho, Wo), Wo % 4 == 0: the final mask upsample

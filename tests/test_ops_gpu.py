@@ -275,6 +275,29 @@ def test_param_cache_refresh(ops):
     ops.CACHE.invalidate()
 
 
+def test_param_cache_refresh_stacked_operands(ops):
+    """Two Linear weights stacked for one GEMM (CACHE.cat, plain and transposed): the batched refresh fills the two row / column blocks of
+    the ONE cached operand in place from the two updated masters -- no torch.cat, no re-allocation -- and a changed master without a
+    refresh is still noticed lazily."""
+    ops.CACHE.invalidate()
+    wa, wb, other = _p(192, 256, seed=1), _p(96, 256, seed=2), _p(64, 128, seed=3)
+    c0, t0, m0 = ops.CACHE.cat(wa, wb), ops.CACHE.cat(wa, wb, transposed=True), ops.CACHE.mat(other)
+    want = lambda: torch.cat([wa.detach(), wb.detach()], 0).to(torch.bfloat16)
+    assert torch.equal(c0, want()) and torch.equal(t0, want().t())
+    for step in range(2):
+        with torch.no_grad():
+            wa.mul_(1.5); wb.add_(0.25); other.add_(1.0)
+        ops.CACHE.refresh()
+        c1, t1 = ops.CACHE.cat(wa, wb), ops.CACHE.cat(wa, wb, transposed=True)
+        assert c1.data_ptr() == c0.data_ptr() and t1.data_ptr() == t0.data_ptr()           # refreshed in place
+        assert torch.equal(c1, want()) and torch.equal(t1, want().t())
+        assert torch.equal(ops.CACHE.mat(other), other.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        wb.add_(1.0)                                                                       # no refresh: the version check re-makes it
+    assert torch.equal(ops.CACHE.cat(wa, wb), want()) and torch.equal(ops.CACHE.cat(wa, wb, transposed=True), want().t())
+    ops.CACHE.invalidate()
+
+
 def test_wgrad_queue_grouped_launch(ops):
     """Deferred, grouped weight gradients == the immediate per-GEMM path (both tile classes, ragged N / K, several
     token-range splits, accumulation into existing .grad, bias sums)."""

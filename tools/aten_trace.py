@@ -22,11 +22,11 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=4) if e.key.startswith("aten::") and (getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)) > 0]
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12) if e.key.startswith("aten::") and (getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)) > 0]
 tm = lambda e: getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
 rows.sort(key=lambda e: -tm(e))
 tot = sum(tm(e) for e in rows)
 print(f"aten ops with device time: {tot / 1e3:.2f} ms")
-for e in rows[:45]:
-    st = [s for s in (e.stack or []) if "uenc" in s or "bench" in s][:2]
-    print(f"{tm(e) / 1e3:7.3f} ms {e.count:4d} x {e.key:28s} {str(e.input_shapes)[:70]:70s} {' | '.join(s.split('/')[-1][:60] for s in st)}")
+for e in rows[:70]:
+    st = [s for s in (e.stack or []) if ("uenc" in s or "bench.py" in s) and "aten_trace" not in s][:3]
+    print(f"{tm(e) / 1e3:7.3f} ms {e.count:4d} x {e.key:24s} {str(e.input_shapes)[:58]:58s} {' <- '.join(s.split('/')[-1].split(',')[0][:48] for s in st)}")

@@ -196,6 +196,8 @@ extern "C" int uenc_attn_mask(const float* logits, uint8_t* mask, long rows, int
 // Batched refresh of the bf16 operand copies of many fp32 master weights in ONE launch (plain or transposed), instead
 // of ~650 tiny cast launches per training step.  `table` (device memory) holds one descriptor per tensor; a 64x64 tile
 // index is mapped to its tensor by binary search over the exclusive prefix sum of tile counts.
+// `transpose`: bit 0 = write the transpose; bits 4.. = leading dimension of dst in elements (0: dense -- cols, or rows when transposed), so that
+// several sources can fill row / column blocks of ONE destination (two Linear weights stacked for a single GEMM).
 struct CastDesc { const float* src; bf16* dst; int rows, cols, transpose, tiles_c; long tile_begin; };
 
 __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restrict__ table, int n, long total_tiles) {
@@ -206,12 +208,14 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restr
             const int mid = (lo + hi + 1) >> 1;
             if (table[mid].tile_begin <= tix) lo = mid; else hi = mid - 1;
         }
-        const CastDesc d = table[lo];
+        CastDesc d = table[lo];
+        const long ldd = (d.transpose >> 4) ? (long)(d.transpose >> 4) : (long)((d.transpose & 1) ? d.rows : d.cols);
+        d.transpose &= 1;
         const int local = (int)(tix - d.tile_begin);
         const int tr = local / d.tiles_c, tc = local - tr * d.tiles_c;
         const int r0 = tr * 64, c0 = tc * 64;
         const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-        if (!d.transpose && (d.cols & 3) == 0 && ((((uintptr_t)d.src) & 15) | (((uintptr_t)d.dst) & 7)) == 0) {
+        if (!d.transpose && (d.cols & 3) == 0 && (ldd & 3) == 0 && ((((uintptr_t)d.src) & 15) | (((uintptr_t)d.dst) & 7)) == 0) {
             // 16 bytes in, 8 bytes out per lane: 16 lanes per 64-column row segment, 16 rows per pass
             const int cx = c0 + (threadIdx.x & 15) * 4;
             for (int i = threadIdx.x >> 4; i < 64; i += 16) {
@@ -219,13 +223,13 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restr
                 if (r < d.rows && cx < d.cols) {
                     const float4 v = *(const float4*)(d.src + (long)r * d.cols + cx);
                     bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
-                    *(bf16x4*)(d.dst + (long)r * d.cols + cx) = o;
+                    *(bf16x4*)(d.dst + (long)r * ldd + cx) = o;
                 }
             }
         } else if (!d.transpose) {
             for (int i = ty; i < 64; i += 4) {
                 const int r = r0 + i, c = c0 + tx;
-                if (r < d.rows && c < d.cols) d.dst[(long)r * d.cols + c] = (bf16)d.src[(long)r * d.cols + c];
+                if (r < d.rows && c < d.cols) d.dst[(long)r * ldd + c] = (bf16)d.src[(long)r * d.cols + c];
             }
         } else {
             __syncthreads();
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restr
                 tile[i][tx] = (r < d.rows && c < d.cols) ? d.src[(long)r * d.cols + c] : 0.f;
             }
             __syncthreads();
-            if ((d.rows & 3) == 0 && (((uintptr_t)d.dst) & 7) == 0) {       // 8 bytes out per lane: 16 lanes per 64-row output segment
+            if ((d.rows & 3) == 0 && (ldd & 3) == 0 && (((uintptr_t)d.dst) & 7) == 0) {       // 8 bytes out per lane: 16 lanes per 64-row output segment
                 const int rx = (threadIdx.x & 15) * 4;
                 for (int i = threadIdx.x >> 4; i < 64; i += 16) {
                     const int c = c0 + i, r = r0 + rx;
@@ -242,13 +246,13 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const CastDesc* __restr
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (bf16)tile[rx + e][i];
-                        *(bf16x4*)(d.dst + (long)c * d.rows + r) = o;
+                        *(bf16x4*)(d.dst + (long)c * ldd + r) = o;
                     }
                 }
             } else {
                 for (int i = ty; i < 64; i += 4) {
                     const int c = c0 + i, r = r0 + tx;
-                    if (c < d.cols && r < d.rows) d.dst[(long)c * d.rows + r] = (bf16)tile[tx][i];
+                    if (c < d.cols && r < d.rows) d.dst[(long)c * ldd + r] = (bf16)tile[tx][i];
                 }
             }
         }

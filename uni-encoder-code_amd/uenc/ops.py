@@ -82,8 +82,9 @@ class ParamCache:
         plan = ((rows[0] if rows else 0) * Kd * 4, N, Kd, 1) if (aligned and not K.EXACT) else None
         return self._get(p, ("t", rows), make, plan)
 
-    def _get2(self, p1, p2, kind, make):
-        """Like _get for an operand derived from two parameters (valid while neither changed)."""
+    def _get2(self, p1, p2, kind, make, plan=None):
+        """Like _get for an operand derived from two parameters (valid while neither changed).  plan: a LIST of
+        (source byte pointer, destination element offset, rows, cols, transpose | ld << 4) pieces for the batched refresh."""
         key = (id(p1), (kind, id(p2)))
         ent = self._store.get(key)
         sig = (p1._version, p1.data_ptr(), p2._version, p2.data_ptr())
@@ -91,17 +92,27 @@ class ParamCache:
             return ent[2]
         t = make()
         self.casts += 1
-        self._store[key] = (sig, p1.data_ptr(), t, weakref.ref(p1), None, weakref.ref(p2))
+        self._store[key] = (sig, p1.data_ptr(), t, weakref.ref(p1), plan, weakref.ref(p2))
         self._table = None
         return t
 
     def cat(self, p1: torch.Tensor, p2: torch.Tensor, transposed: bool = False) -> torch.Tensor:
         """bf16 [p1; p2] stacked along the output dimension ((N1+N2, K), or its (K, N1+N2) transpose): two Linear layers that
-        read the same input run as one GEMM."""
+        read the same input run as one GEMM.  Refreshed by the batched cast like any single weight: the two masters are two
+        descriptors that fill row (column) blocks of the one destination -- no torch.cat, no cast launch of its own per step."""
+        N1, N2 = p1.shape[0], p2.shape[0]
+        Kd = p1.numel() // N1
+
         def make():
-            w = torch.cat([p1.detach().reshape(p1.shape[0], -1), p2.detach().reshape(p2.shape[0], -1)], 0).contiguous()
+            w = torch.cat([p1.detach().reshape(N1, -1), p2.detach().reshape(N2, -1)], 0).contiguous()
             return K.cast_transpose_bf16(w) if transposed else K.cast_bf16(w)
-        return self._get2(p1, p2, "catT" if transposed else "cat", make)
+        plan = None
+        if (not K.EXACT and p1.is_contiguous() and p2.is_contiguous() and p2.numel() // N2 == Kd and Kd % 8 == 0 and N1 % 8 == 0 and N2 % 8 == 0
+                and p1.dtype == F32 and p2.dtype == F32):
+            ld = N1 + N2
+            plan = ([(p1.data_ptr(), 0, N1, Kd, 1 | (ld << 4)), (p2.data_ptr(), N1, N2, Kd, 1 | (ld << 4))] if transposed
+                    else [(p1.data_ptr(), 0, N1, Kd, 0), (p2.data_ptr(), N1 * Kd, N2, Kd, 0)])
+        return self._get2(p1, p2, "catT" if transposed else "cat", make, plan)
 
     def catvec(self, p1: torch.Tensor, p2: torch.Tensor) -> torch.Tensor:
         return self._get2(p1, p2, "catv", lambda: torch.cat([p1.detach(), p2.detach()]).float().contiguous())
@@ -116,29 +127,42 @@ class ParamCache:
         WGRADS.reset()                              # start of a step: nothing of an earlier (failed) backward may survive
         if not self._store:
             return
-        dead = [k for k, e in self._store.items() if e[3]() is None or e[4] is None or e[3]().data_ptr() != e[1]]
+        dead = [k for k, e in self._store.items() if e[3]() is None or e[4] is None or e[3]().data_ptr() != e[1]
+                or (len(e) > 5 and (e[5]() is None or e[5]().data_ptr() != e[0][3]))]
         for k in dead:                              # padded / special entries and moved storages are re-made lazily
             del self._store[k]
             self._table = None
         if not self._store:
             return
         if self._table is None:
-            desc = np.zeros(len(self._store), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
-                                                     ("tr", "<i4"), ("tc", "<i4"), ("tb", "<i8")])
-            tb, keys, dev = 0, [], None
-            for i, (k, e) in enumerate(self._store.items()):
-                off, rows, cols, tr = e[4]
-                desc[i] = (e[1] + off, e[2].data_ptr(), rows, cols, tr, -(-cols // 64), tb)
-                tb += -(-rows // 64) * -(-cols // 64)
+            pieces, keys, dev = [], [], None
+            for k, e in self._store.items():
+                if isinstance(e[4], list):                      # an operand stacked from two masters: one piece per master
+                    for src, doff, rows, cols, tr in e[4]:
+                        pieces.append((src, e[2].data_ptr() + 2 * doff, rows, cols, tr))
+                else:
+                    off, rows, cols, tr = e[4]
+                    pieces.append((e[1] + off, e[2].data_ptr(), rows, cols, tr))
                 keys.append(k)
                 dev = e[2].device
+            desc = np.zeros(len(pieces), dtype=[("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                                ("tr", "<i4"), ("tc", "<i4"), ("tb", "<i8")])
+            tb = 0
+            for i, (src, dst, rows, cols, tr) in enumerate(pieces):
+                desc[i] = (src, dst, rows, cols, tr, -(-cols // 64), tb)
+                tb += -(-rows // 64) * -(-cols // 64)
             tab = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
-            self._table = (tab, len(keys), tb, keys)
+            keys = (keys, len(pieces))
+            self._table = (tab, keys[1], tb, keys[0])
         tab, n, total, keys = self._table
         check(lib.uenc_cast_multi(tab.data_ptr(), n, total, stream_ptr()), "cast_multi")
         for k in keys:
             e = self._store[k]
-            self._store[k] = (e[3]()._version, e[1], e[2], e[3], e[4])
+            if len(e) > 5:
+                p1, p2 = e[3](), e[5]()
+                self._store[k] = ((p1._version, p1.data_ptr(), p2._version, p2.data_ptr()), e[1], e[2], e[3], e[4], e[5])
+            else:
+                self._store[k] = (e[3]()._version, e[1], e[2], e[3], e[4])
 
 
 CACHE = ParamCache()
