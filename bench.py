@@ -238,8 +238,8 @@ def dp_check(model, buckets, batches, step_fn, rank, world, device):
     step_fn(batches[rank])
     torch.cuda.synchronize()
     reduced = buckets.flat.clone()
-    saved_world = buckets.world
-    buckets.world = 1                                  # local passes: no collective, no averaging
+    saved_world, saved_coll = buckets.world, buckets._collective
+    buckets.world, buckets._collective = 1, False      # local passes: no collective, no averaging
     acc = torch.zeros_like(reduced)
     for r in range(world):
         step_fn(batches[r])
@@ -247,7 +247,7 @@ def dp_check(model, buckets, batches, step_fn, rank, world, device):
     acc /= world
     step_fn(batches[0]); a = buckets.flat.clone()
     step_fn(batches[0]); b = buckets.flat.clone()      # run-to-run noise floor (float atomics order)
-    buckets.world = saved_world
+    buckets.world, buckets._collective = saved_world, saved_coll
     torch.cuda.synchronize()
     per = []
     for i, v in buckets._views.items():
