@@ -15,6 +15,8 @@ either; tests/test_model_gpu.py::test_pixel_decoder_unfused_side_paths drives th
 from typing import Callable, Dict, List, Optional, Union
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -269,9 +271,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 # the whole branch on token matrices: GN + top-down merge in one pass (bf16 out = the conv's patch source),
                 # conv as patch GEMM, GN + ReLU in one pass (bf16 out = the next GEMM's operand)
                 prev = out[-1].permute(0, 2, 3, 1)                                          # (B, Hs, Ws, C) view
-                yy = _conv1x1_gn(_tokens(x), lat, lat.norm, H, W, add_src=prev, add_hw=(H, W), out_dtype=torch.bfloat16)
-                z = ops.conv3x3(yy.view(B, H, W, -1), outc.weight)                          # (B, HW, C) fp32
-                last_tok = ops.group_norm_tokens(z, outc.norm, relu=True, out_dtype=torch.bfloat16)
+                if os.environ.get("UENC_FPN_CHAIN", "1") != "0":
+                    # conv + GroupNorm as one autograd node each: the GroupNorm's input gradient stays bf16 on its way into the conv's GEMMs
+                    yy = ops.linear_group_norm(_tokens(x), lat, lat.norm, add_src=prev, add_hw=(H, W), out_dtype=torch.bfloat16)
+                    last_tok = ops.conv3x3_group_norm(yy.view(B, H, W, -1), outc.weight, outc.norm, relu=True, out_dtype=torch.bfloat16)
+                else:                                                                       # (the two-node form, A/B)
+                    yy = _conv1x1_gn(_tokens(x), lat, lat.norm, H, W, add_src=prev, add_hw=(H, W), out_dtype=torch.bfloat16)
+                    z = ops.conv3x3(yy.view(B, H, W, -1), outc.weight)                      # (B, HW, C) fp32
+                    last_tok = ops.group_norm_tokens(z, outc.norm, relu=True, out_dtype=torch.bfloat16)
                 out.append(last_tok.view(B, H, W, -1).permute(0, 3, 1, 2))
                 continue
             last_tok = None

@@ -1304,6 +1304,72 @@ def conv3x3(x_nhwc, weight):
     return Conv3x3Fn.apply(x_nhwc, weight)
 
 
+class _SubCtx:
+    """The part of an autograd ctx the Functions above use, for running one Function inside another (below)."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = tuple(needs)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class LinearGroupNormFn(torch.autograd.Function):
+    """1x1 conv (Linear, fp32 result) -> GroupNorm (+ bilinear top-down merge | + ReLU) on token matrices as ONE autograd node
+    (reference pixel_decoder/msdeformattn.py:283-302, 343-352: Conv2d with norm=GroupNorm).  The arithmetic is LinearFn's and
+    GroupNormTokensFn's, called in sequence; what the fusion buys is in the backward: the GroupNorm's input gradient stays bf16
+    between the two -- as two nodes the engine cast it to fp32 (the conv output's dtype) and the Linear's backward cast it straight
+    back for its GEMMs: two passes over the (B, HW, C) map per GroupNorm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, G, eps, relu, add_src, add_hw, out_dtype):
+        ca = _SubCtx((ctx.needs_input_grad[0], False, False, False, False, False))
+        y = LinearFn.forward(ca, x, weight, bias, None, None, F32)
+        cb = _SubCtx((True, False, False, False, False, False, ctx.needs_input_grad[8], False, False, False))
+        out = GroupNormTokensFn.forward(cb, y, gamma, beta, G, eps, relu, add_src, add_hw, out_dtype, BF16)
+        ctx.sub = (ca, cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ca, cb = ctx.sub
+        ctx.sub = None
+        g = GroupNormTokensFn.backward(cb, dy)             # g[0]: d(conv output) bf16, g[6]: d(add_src)
+        dx = LinearFn.backward(ca, g[0])[0]
+        return dx, None, None, None, None, None, None, None, g[6], None, None
+
+
+class Conv3x3GroupNormFn(torch.autograd.Function):
+    """3x3 conv (im2col + GEMM, fp32 result) -> GroupNorm (+ ReLU) as one autograd node: see LinearGroupNormFn."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, gamma, beta, G, eps, relu, out_dtype):
+        ca = _SubCtx((ctx.needs_input_grad[0], False))
+        y = Conv3x3Fn.forward(ca, x_nhwc, weight)
+        cb = _SubCtx((True, False, False, False, False, False, False, False, False, False))
+        out = GroupNormTokensFn.forward(cb, y, gamma, beta, G, eps, relu, None, None, out_dtype, BF16)
+        ctx.sub = (ca, cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ca, cb = ctx.sub
+        ctx.sub = None
+        g = GroupNormTokensFn.backward(cb, dy)
+        dx = Conv3x3Fn.backward(ca, g[0])[0]
+        return dx, None, None, None, None, None, None, None
+
+
+def linear_group_norm(x, conv, gn, *, relu=False, add_src=None, add_hw=None, out_dtype=F32):
+    """conv: a 1x1 Conv2d / Linear (weight, bias); gn: nn.GroupNorm.  -> (B, HW, C)."""
+    return LinearGroupNormFn.apply(x, conv.weight, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, add_src, add_hw, out_dtype)
+
+
+def conv3x3_group_norm(x_nhwc, weight, gn, *, relu=False, out_dtype=F32):
+    return Conv3x3GroupNormFn.apply(x_nhwc, weight, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, out_dtype)
+
+
 # --------------------------------------------------------------------------------------------
 # DiNAT (SURVEY.md §8a A9): neighbourhood attention, the whole NATLayer, the 3x3 stride-2 convolutions
 # --------------------------------------------------------------------------------------------
