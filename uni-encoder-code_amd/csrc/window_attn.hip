@@ -124,11 +124,15 @@ __device__ __forceinline__ void stage_images(unsigned char* const (&img)[NIMG], 
         }
 }
 
-template <int NTILES>
+// LDSB (12 x 12 windows): the bias comes from a 529-entry LDS copy of the head's table (gathered from the dense bias while the q / k / v
+// rows are in flight) instead of 83 KB of dense [q][key] rows per window-head -- three times the bytes of its q, k and v.  Same values.
+template <int NTILES, bool LDSB>
 __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
+    static_assert(!LDSB || NTILES == 9, "the LDS bias table is laid out for ws = 12");
     using Cf = WCfg<NTILES>;
     constexpr int NTH = Cf::NTH, NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * NK2 * 64 + NK2 * 4 + NK2];
+    constexpr int OFF_BT = (3 * NK2 * 64 + NK2 * 4 + NK2 + 15) / 16 * 16;      // LDSB: float rev[532], rev[528 - t] = log2(e) * table[t][head]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_BT + (LDSB ? 532 * 4 : 0)];
     unsigned char* Qs = smem;
     unsigned char* Ks = smem + NK2 * 64;
     unsigned char* Vs = smem + 2 * NK2 * 64;
@@ -144,6 +148,14 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
     const int C = p.C, hoff = head * 32;
     const long C3 = 3 * (long)p.C;
 
+    float tabv = 0.f;                                  // LDSB: table entry t = threadIdx.x = (dy + 11) * 23 + dx + 11, from q = (max(dy,0), max(dx,0)), key = q - (dy,dx)
+    if constexpr (LDSB) {
+        if (threadIdx.x < 529) {
+            const int t = threadIdx.x, dy = t / 23 - 11, dx = t % 23 - 11;
+            const int qy = dy > 0 ? dy : 0, qx = dx > 0 ? dx : 0;
+            tabv = p.bias_q[((long)head * NP + qy * 12 + qx) * NP + (qy - dy) * 12 + (qx - dx)];
+        }
+    }
     window_slots<NK2>(p, b, wi, wj, tokoff, rid, nullptr, NTH);
     __syncthreads();
     {
@@ -152,6 +164,9 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
         const long stride[3] = {C3, C3, C3};
         const bf16* const pad[3] = {p.qkv_bias + hoff, p.qkv_bias + C + hoff, p.qkv_bias + 2 * C + hoff};
         stage_images<3, NK2, NTH>(img, base, stride, pad, tokoff);
+    }
+    if constexpr (LDSB) {
+        if (threadIdx.x < 529) ((float*)(smem + OFF_BT))[528 - threadIdx.x] = tabv;
     }
     __syncthreads();
 
@@ -166,11 +181,19 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
 
     const float sc = p.scale * LOG2E;
     const float* brow = p.bias_q + ((long)head * NP + qi) * NP;
+    const float* revq = (const float*)(smem + OFF_BT) + (528 - ((qi / 12 + 11) * 23 + qi % 12 + 11));     // + 23 ky + kx: the four keys of a lane are consecutive
     const int ridq = rid[qi];
     float mx = -1e30f;
 #pragma unroll
     for (int kt = 0; kt < NTILES; ++kt) {
-        const float4 bb = *(const float4*)(brow + kt * 16 + 4 * fg);
+        float4 bb;
+        if constexpr (LDSB) {
+            const int key0 = kt * 16 + 4 * fg;
+            const float* rb = revq + (key0 / 12) * 23 + key0 % 12;
+            bb = make_float4(rb[0], rb[1], rb[2], rb[3]);
+        } else {
+            bb = *(const float4*)(brow + kt * 16 + 4 * fg);
+        }
         s[kt][0] = s[kt][0] * sc + bb.x; s[kt][1] = s[kt][1] * sc + bb.y;
         s[kt][2] = s[kt][2] * sc + bb.z; s[kt][3] = s[kt][3] * sc + bb.w;
         if (masked) {
@@ -232,8 +255,13 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
 //     wattn_dtable_kernel then sums the partials over g and along the diagonals (q - key = const) into the table gradient.
 __device__ __attribute__((aligned(16))) unsigned int g_wattn_zero16[4];      // a 16-byte chunk of zeros (rows beyond N, dO pad rows)
 
-template <int NTILES>
+//   * LDSB (12 x 12 windows): the relative-position bias of phase A is looked up in a 529-entry LDS copy of the head's table
+//     instead of being loaded as dense [q][key] rows from L2 (83 KB per window-head, more than its q / k / v / dO): an ordinary
+//     global load whose result is used while the next window's LDS-DMA is in flight makes the wave wait for vmcnt(0), i.e. for
+//     that whole DMA, in the middle of phase A (loads retire in order).  Same values, bit-identical results.
+template <int NTILES, bool LDSB>
 __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) {
+    static_assert(!LDSB || NTILES == 9, "the LDS bias table is laid out for ws = 12 (N = NP = 144, key quads never straddle a window row)");
     using Cf = WCfg<NTILES>;
     constexpr int NTH = Cf::NTH, NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
     constexpr int IMG = NK2 * 64, STAGE = 4 * IMG;
@@ -243,6 +271,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
     constexpr int OFF_PAD = OFF_DEL + NK2 * 4;         // float padacc[96]
     constexpr int OFF_P = OFF_PAD + 96 * 4;            // bf16 P[key tile][NK2 query rows][16 keys]: the softmax of phase A, read back
     constexpr int PSUB = NK2 * 32;                     //   transposed (ds_read_b64_tr_b16) as the P / dS operand tiles of phase B
+    constexpr int OFF_BT = OFF_P + NTILES * PSUB;      // LDSB: float rev[532], rev[528 - t] = log2(e) * table[t][head]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* delta = (float*)(smem + OFF_DEL);
     float* padacc = (float*)(smem + OFF_PAD);          // [3][32] q|k|v bias gradient from padding slots, summed over this WG's windows
@@ -284,6 +313,23 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         }
     };
 
+    // LDSB: entry t = (dy + 11) * 23 + dx + 11 of the head's table, gathered from the dense bias (q = (max(dy,0), max(dx,0)), key = q - (dy,dx))
+    // and stored REVERSED: the four keys 4 fg .. 4 fg + 3 of a lane sit in one window row, so their entries are four consecutive floats
+    const float* rev = (const float*)(smem + OFF_BT);
+    int jb[NTILES];                                    // rev index of (this lane's query, key 16 kt + 4 fg): the same for every window
+    if constexpr (LDSB) {
+        for (int t = threadIdx.x; t < 529; t += NTH) {
+            const int dy = t / 23 - 11, dx = t % 23 - 11;
+            const int qy = dy > 0 ? dy : 0, qx = dx > 0 ? dx : 0;
+            ((float*)(smem + OFF_BT))[528 - t] = p.bias_q[((long)head * NP + qy * 12 + qx) * NP + (qy - dy) * 12 + (qx - dx)];
+        }
+        const int qi0 = wave * 16 + fr, aq = 528 - ((qi0 / 12 + 11) * 23 + qi0 % 12 + 11);
+#pragma unroll
+        for (int kt = 0; kt < NTILES; ++kt) {
+            const int key0 = kt * 16 + 4 * fg;
+            jb[kt] = aq + (key0 / 12) * 23 + key0 % 12;
+        }
+    }
     f32x4 dsacc[NTILES];
 #pragma unroll
     for (int kt = 0; kt < NTILES; ++kt) dsacc[kt] = zero4;
@@ -321,8 +367,10 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         // (all NTILES at once would be 36 more live registers than the 168 a 9-wave workgroup can have)
         const float* brow0 = p.bias_q + ((long)head * NP + wave * 16 + fr) * NP + 4 * fg;
         float4 bnext[3];
+        if constexpr (!LDSB) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
+            for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
+        }
         const bf16x8 ov = o_next;
         if (more) slots(win + G, st ^ 1);
         // This wave's share of the current stage has landed: for the first window by the wait here; for the others by the wait in
@@ -355,11 +403,19 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
 #pragma unroll
             for (int k3 = 0; k3 < NTILES; k3 += 3) {
                 float4 bcur[3];
+                if constexpr (LDSB) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
-                if (k3 + 3 < NTILES) {
+                    for (int j = 0; j < 3; ++j) {
+                        const float* rb = rev + jb[k3 + j < NTILES ? k3 + j : 0];
+                        bcur[j] = make_float4(rb[0], rb[1], rb[2], rb[3]);
+                    }
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (k3 + 3 + j < NTILES ? k3 + 3 + j : 0) * 16);
+                    for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
+                    if (k3 + 3 < NTILES) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (k3 + 3 + j < NTILES ? k3 + 3 + j : 0) * 16);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -644,7 +700,11 @@ static int fill_params(WAttn& p, const void* qkv, const void* qkv_bias, const fl
 template <int NT>
 static void launch_fwd(const WAttn& p, hipStream_t stream) {
     const unsigned grid = (unsigned)((p.nWinTotal + 7) / 8 * 8 * p.nH);
-    hipLaunchKernelGGL(wattn_fwd_kernel<NT>, dim3(grid), dim3(64 * NT), 0, stream, p);
+    constexpr bool HAS_LDSB = NT == 9;
+    if (HAS_LDSB && !(p.variant & 2))                  // bit 1 of UENC_WATTN_VARIANT: dense bias rows from L2 (A/B)
+        hipLaunchKernelGGL((wattn_fwd_kernel<NT, HAS_LDSB>), dim3(grid), dim3(64 * NT), 0, stream, p);
+    else
+        hipLaunchKernelGGL((wattn_fwd_kernel<NT, false>), dim3(grid), dim3(64 * NT), 0, stream, p);
 }
 // groups per head: ~one resident workgroup per CU for the 9-wave (12 x 12) case, more for small windows
 static int wattn_bwd_groups(int nWinTotal, int nH, int ntiles) {
@@ -660,16 +720,22 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
     using Cf = WCfg<NT>;
     constexpr int NK2 = Cf::NK2;
     const int G = wattn_bwd_groups(p.nWinTotal, p.nH, NT);
-    constexpr size_t shm = ((size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 15) / 16 * 16 + NK2 * 4 + 96 * 4 + (size_t)NT * NK2 * 32;
+    constexpr size_t shm = ((size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 15) / 16 * 16 + NK2 * 4 + 96 * 4 + (size_t)NT * NK2 * 32 + 532 * 4;
+    constexpr bool HAS_LDSB = NT == 9;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e == hipSuccess && HAS_LDSB)
+            e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
-    hipLaunchKernelGGL(wattn_bwd_kernel<NT>, dim3(grid), dim3(64 * NT), shm, stream, p, G);
+    if (HAS_LDSB && !(p.variant & 2))                  // bit 1 of UENC_WATTN_VARIANT: dense bias rows from L2 (A/B)
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
+    else
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, false>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
     if (!defer_dtable)
         hipLaunchKernelGGL(wattn_dtable_kernel<NT>, dim3((unsigned)(p.nH * NT)), dim3(256), 0, stream, (const float*)p.dtab_ws, dtab, G,
                            p.nH, p.ws);
