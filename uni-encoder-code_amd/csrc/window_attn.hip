@@ -63,19 +63,21 @@ struct WCfg {
 __device__ __forceinline__ int region3(int v, int P, int ws, int shift) { return (v >= P - ws) + (v >= P - shift); }
 
 // slot bookkeeping: tokoff = flat token index, -1 padding slot, -2 beyond the window's N tokens
-template <int NK2>
+// WS12: the window size is the compile-time 12 of the 9-tile kernels (the per-slot divisions become multiplies)
+template <int NK2, bool WS12 = false>
 __device__ __forceinline__ void window_slots(const WAttn& p, int b, int wi, int wj, int* tokoff, unsigned char* rid,
                                              unsigned short* yx, int nthreads) {
+    const int ws = WS12 ? 12 : p.ws;
     for (int t = threadIdx.x; t < NK2; t += nthreads) {
         int off = -2, r = 0, code = 0;
-        if (t < p.N) {
-            const int ty = t / p.ws, tx = t - ty * p.ws;
-            const int hs = wi * p.ws + ty, wx = wj * p.ws + tx;
+        if (t < (WS12 ? 144 : p.N)) {
+            const int ty = t / ws, tx = t - ty * ws;
+            const int hs = wi * ws + ty, wx = wj * ws + tx;
             int ho = hs + p.shift, wo = wx + p.shift;
             if (ho >= p.Hp) ho -= p.Hp;
             if (wo >= p.Wp) wo -= p.Wp;
             off = (ho < p.H && wo < p.W) ? (b * p.H + ho) * p.W + wo : -1;
-            if (p.shift > 0) r = 3 * region3(hs, p.Hp, p.ws, p.shift) + region3(wx, p.Wp, p.ws, p.shift);
+            if (p.shift > 0) r = 3 * region3(hs, p.Hp, ws, p.shift) + region3(wx, p.Wp, ws, p.shift);
             code = (ty << 8) | tx;
         }
         tokoff[t] = off;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
             tabv = p.bias_q[((long)head * NP + qy * 12 + qx) * NP + (qy - dy) * 12 + (qx - dx)];
         }
     }
-    window_slots<NK2>(p, b, wi, wj, tokoff, rid, nullptr, NTH);
+    window_slots<NK2, NTILES == 9>(p, b, wi, wj, tokoff, rid, nullptr, NTH);
     __syncthreads();
     {
         unsigned char* const img[3] = {Qs, Ks, Vs};
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
     auto slots = [&](int win, int st) {
         const int b = win / p.nWin, wrem = win - b * p.nWin;
         const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
-        window_slots<NK2>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
+        window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
     };
     // LDS-DMA of one window's q, k, v, dO images: 16 rows (1 KB) per wave instruction
     auto issue = [&](int st) {
