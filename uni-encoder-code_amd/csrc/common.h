@@ -55,6 +55,25 @@ __device__ __forceinline__ float group8_sum(float v) {
     v = dpp_add_f32<0x4E>(v);
     return dpp_add_f32<0x141>(v);
 }
+// x[i] (op) x[i ^ 16] and x[i] (op) x[i ^ 32] on v_permlane16_swap / v_permlane32_swap (gfx950): swapping a register with itself
+// leaves every lane with its own value in one result and its partner's in the other, so a commutative op of the two is the
+// butterfly step -- one VALU instruction instead of the LDS-crossbar round trip of ds_bpermute_b32 that __shfl_xor compiles to.
+__device__ __forceinline__ float xor16_sum(float v) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void mha_q_kernel(MhaP p) {
                     for (int j = 0; j < 8; ++j) part += (float)ov[j] * (float)dof[i][j];
                     lse_q[i] = p.lse[((long)b * p.H + h) * p.Lq + qidx[i]];
                 }
-                part += __shfl_xor(part, 16);
-                part += __shfl_xor(part, 32);
+                part = xor16_sum(part);
+                part = xor32_sum(part);
                 dl_q[i] = part;
             }
         }
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void mha_q_kernel(MhaP p) {
                 mloc = vmax3f(mloc, v[0][3], v[1][0]); mloc = vmax3f(mloc, v[1][1], v[1][2]); mloc = vmax3f(mloc, v[1][3], v[2][0]);
                 mloc = vmax3f(mloc, v[2][1], v[2][2]); mloc = vmax3f(mloc, v[2][3], v[3][0]); mloc = vmax3f(mloc, v[3][1], v[3][2]);
                 mloc = vmaxf(mloc, v[3][3]);
-                mloc = vmaxf(mloc, __shfl_xor(mloc, 16));
-                mloc = vmaxf(mloc, __shfl_xor(mloc, 32));
+                mloc = xor16_max(mloc);
+                mloc = xor32_max(mloc);
                 const float mnew = vmaxf(m_run[i], mloc * sc);        // (-inf * sc = -inf: a block with nothing visible keeps the running maximum)
                 const float alpha = fast_exp2(m_run[i] - mnew);
                 const float nm = -mnew;
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void mha_q_kernel(MhaP p) {
                             v[kt][r] = attn_keep(p.seed, p.drop_thresh, ((unsigned long long)bh * p.Lq + qidx[i]) * p.S + (kbase + kt * 16 + 4 * fg + r))
                                            ? e * p.inv_keep : 0.f;
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                sum = xor16_sum(sum);
+                sum = xor32_sum(sum);
                 l_run[i] = l_run[i] * alpha + sum;
                 m_run[i] = mnew;
 #pragma unroll

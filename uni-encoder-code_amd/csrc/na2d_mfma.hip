@@ -260,8 +260,8 @@ __global__ __launch_bounds__(512) void na2d_mfma_fwd_kernel(Na2d p) {
                     m = fmaxf(m, s[kt][r]);
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
+            m = xor16_max(m);
+            m = xor32_max(m);
             float l = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(512) void na2d_mfma_fwd_kernel(Na2d p) {
                     s[kt][r] = fast_exp2(s[kt][r] - m);
                     l += s[kt][r];
                 }
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
+            l = xor16_sum(l);
+            l = xor32_sum(l);
             f32x4 o[2] = {zero4, zero4};
 #pragma unroll
             for (int s2 = 0; s2 < NKT / 2; ++s2) {
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(512) void na2d_mfma_bwd_q_kernel(Na2d p) {
             float delta = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) delta += (float)dof[c] * (float)ov[c];
-            delta += __shfl_xor(delta, 16);
-            delta += __shfl_xor(delta, 32);
+            delta = xor16_sum(delta);
+            delta = xor32_sum(delta);
             if (q.valid && fg == 0) delta_b[q.pix] = delta;
             if (p.drpb) {
                 const int by_first = __builtin_amdgcn_readfirstlane(q.by0);       // lane 0 = the wave's first query (row 0, column 0)

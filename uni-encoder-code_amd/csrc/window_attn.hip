@@ -66,9 +66,9 @@ __device__ __forceinline__ int region3(int v, int P, int ws, int shift) { return
 // WS12: the window size is the compile-time 12 of the 9-tile kernels (the per-slot divisions become multiplies)
 template <int NK2, bool WS12 = false>
 __device__ __forceinline__ void window_slots(const WAttn& p, int b, int wi, int wj, int* tokoff, unsigned char* rid,
-                                             unsigned short* yx, int nthreads) {
+                                             unsigned short* yx, int nthreads, int tid = -1) {
     const int ws = WS12 ? 12 : p.ws;
-    for (int t = threadIdx.x; t < NK2; t += nthreads) {
+    for (int t = tid < 0 ? (int)threadIdx.x : tid; t < NK2; t += nthreads) {
         int off = -2, r = 0, code = 0;
         if (t < (WS12 ? 144 : p.N)) {
             const int ty = t / ws, tx = t - ty * ws;
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
         }
         mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = xor16_max(mx);
+    mx = xor32_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NTILES; ++kt)
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
             s[kt][r] = e;
             sum += e;
         }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = xor16_sum(sum);
+    sum = xor32_sum(sum);
     const float inv = 1.0f / sum;
 
     f32x4 o[2] = {zero4, zero4};
@@ -261,11 +261,20 @@ __device__ __attribute__((aligned(16))) unsigned int g_wattn_zero16[4];      // 
 //     instead of being loaded as dense [q][key] rows from L2 (83 KB per window-head, more than its q / k / v / dO): an ordinary
 //     global load whose result is used while the next window's LDS-DMA is in flight makes the wave wait for vmcnt(0), i.e. for
 //     that whole DMA, in the middle of phase A (loads retire in order).  Same values, bit-identical results.
-template <int NTILES, bool LDSB>
-__global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) {
+//   * LOADER: a TENTH wave does nothing but the slot bookkeeping and the LDS-DMA of the next window.  In-kernel s_memtime stamps
+//     (profiles/r03_wattn_bwd_experiments.txt) showed every compute wave spending 16 % of a window inside its share of the DMA issue
+//     (4-5 scattered 1 KB global_load_lds each, all nine waves through the CU's one address path at once) and 7 % in the slot
+//     arithmetic, and then waiting vmcnt(0) for its own DMA in the middle of phase A (loads retire in order behind the DMA).  With
+//     the loader the compute waves issue no DMA at all: their only vector-memory operations are the saved-output prefetch and the
+//     result stores.  The loader takes part in the three barriers of a window: stage landed (its vmcnt(0)) -> top barrier -> slots +
+//     DMA of the NEXT window into the other stage (free since the previous end barrier) -> mid barrier (the slots become visible:
+//     the compute waves prefetch their next saved-output rows) -> end barrier.
+template <int NTILES, bool LDSB, bool LOADER>
+__global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_kernel(WAttn p, int G) {
     static_assert(!LDSB || NTILES == 9, "the LDS bias table is laid out for ws = 12 (N = NP = 144, key quads never straddle a window row)");
     using Cf = WCfg<NTILES>;
-    constexpr int NTH = Cf::NTH, NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
+    constexpr int NWAVES = NTILES + (LOADER ? 1 : 0), NTH = 64 * NWAVES;
+    constexpr int NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
     constexpr int IMG = NK2 * 64, STAGE = 4 * IMG;
     constexpr int OFF_TOK = 2 * STAGE;                 // int tokoff[2][NK2]
     constexpr int OFF_RID = OFF_TOK + 2 * NK2 * 4;     // u8  rid[2][NK2]
@@ -295,23 +304,40 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     typedef __attribute__((address_space(3))) void lds_void;
 
+    const bool loader = LOADER && wave == NTILES;
     auto slots = [&](int win, int st) {
         const int b = win / p.nWin, wrem = win - b * p.nWin;
         const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
-        window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
+        if (LOADER) window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, 64, lane);
+        else window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
     };
     // LDS-DMA of one window's q, k, v, dO images: 16 rows (1 KB) per wave instruction
     auto issue = [&](int st) {
         const int* tok = (const int*)(smem + OFF_TOK) + st * NK2;
         constexpr int PER_IMG = NK2 / 16;
-        for (int ii = wave; ii < 4 * PER_IMG; ii += NTILES) {
-            const int img = ii / PER_IMG, rb = ii - img * PER_IMG;
-            const int row = rb * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
-            const int t = tok[row];
-            const bf16* src = (const bf16*)g_wattn_zero16;
-            if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : p.d_out + (long)t * C) + hoff + chunk * 8;
-            else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
-            __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
+        if constexpr (LOADER) {                        // the loader wave: all four images of a 16-row block from one slot read
+#pragma unroll 2
+            for (int rb = 0; rb < PER_IMG; ++rb) {
+                const int row = rb * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
+                const int t = tok[row];
+#pragma unroll
+                for (int img = 0; img < 4; ++img) {
+                    const bf16* src = (const bf16*)g_wattn_zero16;
+                    if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : p.d_out + (long)t * C) + hoff + chunk * 8;
+                    else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
+                    __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
+                }
+            }
+        } else {
+            for (int ii = wave; ii < 4 * PER_IMG; ii += NTILES) {
+                const int img = ii / PER_IMG, rb = ii - img * PER_IMG;
+                const int row = rb * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
+                const int t = tok[row];
+                const bf16* src = (const bf16*)g_wattn_zero16;
+                if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : p.d_out + (long)t * C) + hoff + chunk * 8;
+                else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
+                __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -345,11 +371,21 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         for (int j = 0; j < 8; ++j) o_next[j] = (bf16)0.f;
     }
     if (win < p.nWinTotal) {
-        slots(win, 0);
-        __syncthreads();
-        issue(0);
-        const int qtok = ((const int*)(smem + OFF_TOK))[wave * 16 + fr];
-        if (qtok >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
+        if (LOADER) {
+            if (loader) {
+                slots(win, 0);                         // written and read back by the same wave: LDS operations of a wave execute in order
+                issue(0);
+            }
+            __syncthreads();
+        } else {
+            slots(win, 0);
+            __syncthreads();
+            issue(0);
+        }
+        if (!loader) {
+            const int qtok = ((const int*)(smem + OFF_TOK))[wave * 16 + fr];
+            if (qtok >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
+        }
     }
     const bool wait_at_top = (p.variant & 1) != 0;          // bit 0: the round-2 placement of the stage wait (A/B)
     for (int it = 0; win < p.nWinTotal; ++it, win += G) {
@@ -374,20 +410,25 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
             for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
         }
         const bf16x8 ov = o_next;
-        if (more) slots(win + G, st ^ 1);
+        if (!LOADER && more) slots(win + G, st ^ 1);
         // This wave's share of the current stage has landed: for the first window by the wait here; for the others by the wait in
         // front of the previous window's dK / dV stores (below).  A wave's vector-memory operations retire in order, so a vmcnt(0)
         // HERE would also wait for those stores to be acknowledged -- with one workgroup per CU nothing else runs meanwhile.
-        if (it == 0 || wait_at_top) __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (LOADER ? loader : (it == 0 || wait_at_top)) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();                               // ... everyone's; next window's slots are visible
-        if (more) {
+        if (LOADER) {
+            if (loader && more) {
+                slots(win + G, st ^ 1);
+                issue(st ^ 1);
+            }
+        } else if (more) {
             issue(st ^ 1);
             const int qtok_n = ((const int*)(smem + OFF_TOK))[(st ^ 1) * NK2 + wave * 16 + fr];
             if (qtok_n >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok_n * C + hoff + 8 * fg);
         }
 
         // ---------------- phase A: this wave's 16 queries x all keys (key-major S^T): statistics, dS, dQ ----------------
-        {
+        if (!loader) {
             const int qt = wave, qi = qt * 16 + fr;
             const int qtok = tokoff[qi];
             const bf16x8 qf = frag_rows(Qs, qt * 16, fr, fg);
@@ -397,8 +438,8 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dl += (float)ov[j] * (float)dof[j];
             }
-            dl += __shfl_xor(dl, 16);
-            dl += __shfl_xor(dl, 32);
+            dl = xor16_sum(dl);
+            dl = xor32_sum(dl);
             f32x4 s[NTILES];
             const int ridq = rid[qi];
             float mx = -1e30f;
@@ -438,8 +479,8 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                 }
                 __builtin_amdgcn_sched_barrier(0);     // bound the loads hoisted ahead (register pressure)
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NTILES; ++kt)
@@ -449,8 +490,8 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
                     s[kt][r] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = xor16_sum(sum);
+            sum = xor32_sum(sum);
             const float inv = 1.0f / sum;
             if (fg == 0) delta[qi] = dl;
             __builtin_amdgcn_sched_barrier(0);
@@ -503,7 +544,11 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         // ---------------- phase B: this wave's 16 keys x all queries: dK, dV ----------------
         // P[q][key] comes back from LDS already in MFMA operand order (hardware transposing read), which is also the accumulator
         // order of dP = dO V^T: dS = P * (dP - delta) needs no score recomputation (no QK^T, bias, mask or exp here)
-        {
+        if (!loader) {
+            if (LOADER && more) {                          // the next window's slots (written by the loader wave) are visible since the barrier above
+                const int qtok_n = ((const int*)(smem + OFF_TOK))[(st ^ 1) * NK2 + wave * 16 + fr];
+                if (qtok_n >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok_n * C + hoff + 8 * fg);
+            }
             const int kt = wave, ki = kt * 16 + fr;
             const int ktok = tokoff[ki];
             const bf16x8 vfB = frag_rows(Vs, kt * 16, fr, fg);
@@ -542,7 +587,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
             // the next window's q / k / v / dO rows (LDS-DMA issued at the top of this iteration) have had both phases to land: waiting for
             // them here, BEFORE this window's last stores enter the queue, costs nothing and leaves the stores to drain under the next
             // window's phase A
-            if (!wait_at_top) __builtin_amdgcn_s_waitcnt(0x0f70);
+            if (!LOADER && !wait_at_top) __builtin_amdgcn_s_waitcnt(0x0f70);
             if (ktok != -2) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -566,9 +611,11 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_bwd_kernel(WAttn p, int G) 
         __syncthreads();   // stage st, lse / delta and tokoff[st] are free for the window after next
     }
     // dense dS partial of this workgroup: [wave = query tile][kt][lane][4]  <->  q = 16 wave + (lane & 15), key = 16 kt + 4 (lane >> 4) + r
-    float* wsp = p.dtab_ws + (((long)head * G + g) * NTILES + wave) * (NP * 16);
+    if (!loader) {
+        float* wsp = p.dtab_ws + (((long)head * G + g) * NTILES + wave) * (NP * 16);
 #pragma unroll
-    for (int kt = 0; kt < NTILES; ++kt) *(f32x4*)(wsp + (kt * 64 + lane) * 4) = dsacc[kt];
+        for (int kt = 0; kt < NTILES; ++kt) *(f32x4*)(wsp + (kt * 64 + lane) * 4) = dsacc[kt];
+    }
     for (int t = threadIdx.x; t < 96; t += NTH) {
         const float v = padacc[t];
         if (v != 0.f) atomicAdd(p.dpad + (t >> 5) * C + hoff + (t & 31), v);
@@ -726,18 +773,23 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
     constexpr bool HAS_LDSB = NT == 9;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e == hipSuccess && HAS_LDSB)
-            e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e == hipSuccess && HAS_LDSB) {
+            e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        }
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
-    if (HAS_LDSB && !(p.variant & 2))                  // bit 1 of UENC_WATTN_VARIANT: dense bias rows from L2 (A/B)
-        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
-    else
-        hipLaunchKernelGGL((wattn_bwd_kernel<NT, false>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
+    if (HAS_LDSB && !(p.variant & 6))                  // 12 x 12 windows: LDS bias table, loader wave
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm, stream, p, G);
+    else if (HAS_LDSB && !(p.variant & 2))             // bit 2 of UENC_WATTN_VARIANT: every wave issues its share of the DMA (A/B)
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, false>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
+    else                                               // bit 1: dense bias rows from L2 as well (A/B)
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, false, false>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
     if (!defer_dtable)
         hipLaunchKernelGGL(wattn_dtable_kernel<NT>, dim3((unsigned)(p.nH * NT)), dim3(256), 0, stream, (const float*)p.dtab_ws, dtab, G,
                            p.nH, p.ws);
