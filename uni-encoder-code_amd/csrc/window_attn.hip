@@ -275,10 +275,12 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     using Cf = WCfg<NTILES>;
     constexpr int NWAVES = NTILES + (LOADER ? 1 : 0), NTH = 64 * NWAVES;
     constexpr int NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
-    constexpr int IMG = NK2 * 64, STAGE = 4 * IMG;
-    constexpr int OFF_TOK = 2 * STAGE;                 // int tokoff[2][NK2]
-    constexpr int OFF_RID = OFF_TOK + 2 * NK2 * 4;     // u8  rid[2][NK2]
-    constexpr int OFF_DEL = (OFF_RID + 2 * NK2 + 15) / 16 * 16;     // float delta[NK2]
+    constexpr int NIMG = LOADER ? 5 : 4;               // q, k, v, dO (+ LOADER: the saved forward output O, for delta)
+    constexpr int IMG = NK2 * 64, STAGE = NIMG * IMG;
+    constexpr int NTB = LOADER ? 3 : 2;                // slot buffers: LOADER keeps the window after next ready as well
+    constexpr int OFF_TOK = 2 * STAGE;                 // int tokoff[NTB][NK2]
+    constexpr int OFF_RID = OFF_TOK + NTB * NK2 * 4;   // u8  rid[NTB][NK2]
+    constexpr int OFF_DEL = (OFF_RID + NTB * NK2 + 15) / 16 * 16;   // float delta[NK2]
     constexpr int OFF_PAD = OFF_DEL + NK2 * 4;         // float padacc[96]
     constexpr int OFF_P = OFF_PAD + 96 * 4;            // bf16 P[key tile][NK2 query rows][16 keys]: the softmax of phase A, read back
     constexpr int PSUB = NK2 * 32;                     //   transposed (ds_read_b64_tr_b16) as the P / dS operand tiles of phase B
@@ -305,15 +307,15 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     typedef __attribute__((address_space(3))) void lds_void;
 
     const bool loader = LOADER && wave == NTILES;
-    auto slots = [&](int win, int st) {
+    auto slots = [&](int win, int st) {                // st: slot buffer
         const int b = win / p.nWin, wrem = win - b * p.nWin;
         const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
         if (LOADER) window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, 64, lane);
         else window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
     };
     // LDS-DMA of one window's q, k, v, dO images: 16 rows (1 KB) per wave instruction
-    auto issue = [&](int st) {
-        const int* tok = (const int*)(smem + OFF_TOK) + st * NK2;
+    auto issue = [&](int st, int tb) {                 // st: stage, tb: slot buffer
+        const int* tok = (const int*)(smem + OFF_TOK) + tb * NK2;
         constexpr int PER_IMG = NK2 / 16;
         if constexpr (LOADER) {                        // the loader wave: all four images of a 16-row block from one slot read
 #pragma unroll 2
@@ -321,9 +323,9 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                 const int row = rb * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
                 const int t = tok[row];
 #pragma unroll
-                for (int img = 0; img < 4; ++img) {
+                for (int img = 0; img < 5; ++img) {
                     const bf16* src = (const bf16*)g_wattn_zero16;
-                    if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : p.d_out + (long)t * C) + hoff + chunk * 8;
+                    if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : (img == 3 ? p.d_out : p.o_saved) + (long)t * C) + hoff + chunk * 8;
                     else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
                     __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
                 }
@@ -374,28 +376,53 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
         if (LOADER) {
             if (loader) {
                 slots(win, 0);                         // written and read back by the same wave: LDS operations of a wave execute in order
-                issue(0);
+                issue(0, 0);
+                if (win + G < p.nWinTotal) slots(win + G, 1);
             }
             __syncthreads();
         } else {
             slots(win, 0);
             __syncthreads();
-            issue(0);
+            issue(0, 0);
         }
-        if (!loader) {
+        if (!LOADER) {
             const int qtok = ((const int*)(smem + OFF_TOK))[wave * 16 + fr];
             if (qtok >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok * C + hoff + 8 * fg);
         }
     }
     const bool wait_at_top = (p.variant & 1) != 0;          // bit 0: the round-2 placement of the stage wait (A/B)
+    // LOADER: the waves talk through LDS only, so a barrier needs this wave's LDS operations done (lgkmcnt) and nothing else; __syncthreads()
+    // would also drain vmcnt wherever an LDS-DMA may be outstanding -- the loader would wait for the DMA it has just issued and the compute
+    // waves for the acknowledgement of their result stores, at every barrier
+    auto wg_barrier = [&]() {
+        if (LOADER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
+    // The loader's loop is separate code: with the LDS-DMA in the compute loop's control flow the compiler must assume one is outstanding
+    // at every LDS read it cannot prove disjoint (every transposing read) and makes the compute waves wait vmcnt(0) there -- for
+    // their own freshly issued result stores.
+    if (loader) {
+        for (int it = 0; win < p.nWinTotal; ++it, win += G) {
+            // slot buffers rotate over three windows: the DMA of window it + 1 (~50 instructions, ~7.5 k cycles: as long as phase A) starts
+            // right behind the top barrier from slots made ready a window earlier; the slots of window it + 2 are computed afterwards
+            const int tb = it % 3, tb1 = tb == 2 ? 0 : tb + 1, tb2 = tb1 == 2 ? 0 : tb1 + 1;
+            __builtin_amdgcn_s_waitcnt(0x0f70);            // the current window's images have landed
+            wg_barrier();
+            if (win + G < p.nWinTotal) issue((it & 1) ^ 1, tb1);
+            wg_barrier();
+            if (win + 2 * G < p.nWinTotal) slots(win + 2 * G, tb2);     // buffer of window it - 1: free since the previous end barrier
+            wg_barrier();
+        }
+    } else
     for (int it = 0; win < p.nWinTotal; ++it, win += G) {
         const int st = it & 1;
         const unsigned char* Qs = smem + st * STAGE;
         const unsigned char* Ks = Qs + IMG;
         const unsigned char* Vs = Qs + 2 * IMG;
         const unsigned char* dOs = Qs + 3 * IMG;
-        const int* tokoff = (const int*)(smem + OFF_TOK) + st * NK2;
-        const unsigned char* rid = smem + OFF_RID + st * NK2;
+        const int tbuf = LOADER ? it % 3 : st;
+        const int* tokoff = (const int*)(smem + OFF_TOK) + tbuf * NK2;
+        const unsigned char* rid = smem + OFF_RID + tbuf * NK2;
         const int b = win / p.nWin, wrem = win - b * p.nWin;
         const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
         const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
@@ -409,30 +436,26 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
 #pragma unroll
             for (int j = 0; j < 3; ++j) bnext[j] = *(const float4*)(brow0 + (j < NTILES ? j : 0) * 16);
         }
-        const bf16x8 ov = o_next;
         if (!LOADER && more) slots(win + G, st ^ 1);
         // This wave's share of the current stage has landed: for the first window by the wait here; for the others by the wait in
         // front of the previous window's dK / dV stores (below).  A wave's vector-memory operations retire in order, so a vmcnt(0)
         // HERE would also wait for those stores to be acknowledged -- with one workgroup per CU nothing else runs meanwhile.
-        if (LOADER ? loader : (it == 0 || wait_at_top)) __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();                               // ... everyone's; next window's slots are visible
-        if (LOADER) {
-            if (loader && more) {
-                slots(win + G, st ^ 1);
-                issue(st ^ 1);
-            }
-        } else if (more) {
-            issue(st ^ 1);
+        if (!LOADER && (it == 0 || wait_at_top)) __builtin_amdgcn_s_waitcnt(0x0f70);
+        const bf16x8 ov_reg = o_next;
+        wg_barrier();                                  // ... everyone's; next window's slots are visible
+        if (!LOADER && more) {
+            issue(st ^ 1, st ^ 1);
             const int qtok_n = ((const int*)(smem + OFF_TOK))[(st ^ 1) * NK2 + wave * 16 + fr];
             if (qtok_n >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok_n * C + hoff + 8 * fg);
         }
 
         // ---------------- phase A: this wave's 16 queries x all keys (key-major S^T): statistics, dS, dQ ----------------
-        if (!loader) {
+        {
             const int qt = wave, qi = qt * 16 + fr;
             const int qtok = tokoff[qi];
             const bf16x8 qf = frag_rows(Qs, qt * 16, fr, fg);
             const bf16x8 dof = frag_rows(dOs, qt * 16, fr, fg);
+            const bf16x8 ov = LOADER ? frag_rows(Qs + 4 * IMG, qt * 16, fr, fg) : ov_reg;      // the same 8 channels of the saved output row (zeros for padding slots)
             float dl = 0.f;                               // delta[q] = sum_d dO[q][d] * O[q][d]
             if (qtok >= 0) {
 #pragma unroll
@@ -539,16 +562,12 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                 }
             }
         }
-        __syncthreads();   // delta and the P image complete
+        wg_barrier();      // delta and the P image complete
 
         // ---------------- phase B: this wave's 16 keys x all queries: dK, dV ----------------
         // P[q][key] comes back from LDS already in MFMA operand order (hardware transposing read), which is also the accumulator
         // order of dP = dO V^T: dS = P * (dP - delta) needs no score recomputation (no QK^T, bias, mask or exp here)
-        if (!loader) {
-            if (LOADER && more) {                          // the next window's slots (written by the loader wave) are visible since the barrier above
-                const int qtok_n = ((const int*)(smem + OFF_TOK))[(st ^ 1) * NK2 + wave * 16 + fr];
-                if (qtok_n >= 0) o_next = *(const bf16x8*)(p.o_saved + (long)qtok_n * C + hoff + 8 * fg);
-            }
+        {
             const int kt = wave, ki = kt * 16 + fr;
             const int ktok = tokoff[ki];
             const bf16x8 vfB = frag_rows(Vs, kt * 16, fr, fg);
@@ -608,7 +627,7 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                 }
             }
         }
-        __syncthreads();   // stage st, lse / delta and tokoff[st] are free for the window after next
+        wg_barrier();      // stage st, lse / delta and tokoff[st] are free for the window after next
     }
     // dense dS partial of this workgroup: [wave = query tile][kt][lane][4]  <->  q = 16 wave + (lane & 15), key = 16 kt + 4 (lane >> 4) + r
     if (!loader) {
@@ -771,13 +790,14 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
     const int G = wattn_bwd_groups(p.nWinTotal, p.nH, NT);
     constexpr size_t shm = ((size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 15) / 16 * 16 + NK2 * 4 + 96 * 4 + (size_t)NT * NK2 * 32 + 532 * 4;
     constexpr bool HAS_LDSB = NT == 9;
+    constexpr size_t shm_loader = shm + (size_t)2 * NK2 * 64 + NK2 * 4 + NK2 + 16;      // + the fifth image of both stages, the third slot buffer
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e == hipSuccess && HAS_LDSB) {
             e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_loader);
         }
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -785,7 +805,7 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
     if (HAS_LDSB && !(p.variant & 6))                  // 12 x 12 windows: LDS bias table, loader wave
-        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm, stream, p, G);
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm_loader, stream, p, G);
     else if (HAS_LDSB && !(p.variant & 2))             // bit 2 of UENC_WATTN_VARIANT: every wave issues its share of the DMA (A/B)
         hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, false>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
     else                                               // bit 1: dense bias rows from L2 as well (A/B)
