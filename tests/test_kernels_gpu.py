@@ -171,8 +171,11 @@ def _window_attn_ref(qkv, qkv_bias, table, H, W, ws, shift, nH):
     return y[:, :L]
 
 
+# the last two geometries give every persistent backward workgroup SEVERAL windows (160 windows on 42 / 21 groups per head): stage
+# alternation, the loader wave's DMA of the next window and its three rotating slot tables (csrc/window_attn.hip) are only exercised then
 @pytest.mark.parametrize("ws,H,W,nH,shift", [(7, 24, 40, 3, 0), (7, 24, 40, 3, 3), (12, 20, 30, 2, 0), (12, 20, 30, 2, 6),
-                                              (12, 24, 36, 1, 6), (3, 7, 8, 1, 1), (5, 9, 11, 2, 2), (8, 16, 16, 1, 4)])
+                                              (12, 24, 36, 1, 6), (3, 7, 8, 1, 1), (5, 9, 11, 2, 2), (8, 16, 16, 1, 4),
+                                              (12, 96, 120, 6, 6), (12, 91, 118, 12, 0)])
 def test_window_attention_fwd_bwd(K, ws, H, W, nH, shift):
     B, C = 2, nH * 32
     qkv = _r(B, H * W, 3 * C, seed=1, scale=1.5, dtype=torch.bfloat16)
@@ -195,6 +198,33 @@ def test_window_attention_fwd_bwd(K, ws, H, W, nH, shift):
     _close(dqkv.view(B, H * W, 3 * C), q32.grad, 3e-2 * gs, 3e-2)
     _close(dtab - dtab0, t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
     _close(dpad - dpad0, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)
+
+
+@pytest.mark.parametrize("H,W,nH,shift", [(96, 120, 6, 6), (40, 50, 24, 0)])
+def test_window_attention_bwd_kernel_forms_agree(K, H, W, nH, shift, monkeypatch):
+    """12 x 12 windows: the loader-wave kernel (production), the nine-wave kernel with the LDS bias table (variant 4) and the one with
+    dense bias rows (variant 2) compute the same arithmetic in the same order: dqkv bit-identical, the two parameter gradients equal
+    up to the order of their float atomics."""
+    B, C, ws = 2, nH * 32, 12
+    qkv = _r(B, H * W, 3 * C, seed=11, scale=1.5, dtype=torch.bfloat16)
+    qb = _r(3 * C, seed=12, scale=0.5, dtype=torch.bfloat16)
+    table = _r((2 * ws - 1) ** 2, nH, seed=13, scale=0.5)
+    bq, bk = K.relpos_expand(table, ws)
+    do = _r(B, H * W, C, seed=14, dtype=torch.bfloat16)
+    got = {}
+    for variant in ("0", "4", "2"):
+        monkeypatch.setenv("UENC_WATTN_VARIANT", variant)
+        out = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), qb, bq, ws, shift, 32 ** -0.5)
+        dtab, dpad = torch.zeros((2 * ws - 1) ** 2, nH, device="cuda"), torch.zeros(3 * C, device="cuda")
+        dqkv = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), qb, bq, bk, out, do.view(B, H, W, C), ws, shift, 32 ** -0.5, dtable=dtab, dbias=dpad)
+        torch.cuda.synchronize()
+        got[variant] = (out.clone(), dqkv.clone(), dtab, dpad)
+    monkeypatch.delenv("UENC_WATTN_VARIANT")
+    for variant in ("4", "2"):
+        assert torch.equal(got["0"][0], got[variant][0]), f"forward differs from variant {variant}"
+        assert torch.equal(got["0"][1], got[variant][1]), f"dqkv differs from variant {variant}"
+        _close(got["0"][2], got[variant][2], 1e-4 * float(got["0"][2].abs().max()) + 1e-6, 1e-4)
+        _close(got["0"][3], got[variant][3], 1e-4 * float(got["0"][3].abs().max()) + 1e-6, 1e-4)
 
 
 def test_msdeform_golden(K):
