@@ -218,6 +218,13 @@ int uenc_patch_merge_ln_bwd(const void* dy, int dy_dtype, const float* x, const 
 int uenc_window_attn_np(int ws); /* padded tokens per window = 16 * ceil(ws*ws / 16) */
 int uenc_relpos_expand(const float* table /* ((2ws-1)^2, nH) */, float* bias_q /* (nH,NP,NP) [h][q][key] */,
                        float* bias_k /* (nH,NP,NP) [h][key][q] */, int nH, int ws, uenc_stream_t stream);
+/* Grouped form: n descriptors in device memory (8-byte aligned), 40 bytes each
+ * { const float* table; float* bias_q; float* bias_k (NULL: not written); int nH, ws, NP, blk_begin; } with NP =
+ * uenc_window_attn_np(ws) and blk_begin = exclusive prefix sum of ceil(nH*NP*NP / 2048); total_blocks = the full sum.  One
+ * launch refreshes the expanded biases of every window-attention module after an optimizer step (the host keeps them keyed by
+ * the table's version: uenc.ops.ParamCache.relpos).  (The window-attention kernels do not read bias_k any more: it may alias
+ * bias_q in their calls.) */
+int uenc_relpos_expand_grouped(const void* table, int n, int total_blocks, uenc_stream_t stream);
 int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
                          int C, int nH, int ws, int shift, float scale, uenc_stream_t stream);
 /* dqkv (B,H,W,3C) bf16 written.  dS_ws: scratch of uenc_window_attn_bwd_ws_floats() floats (dense per-workgroup sums of

@@ -298,6 +298,35 @@ def test_param_cache_refresh_stacked_operands(ops):
     ops.CACHE.invalidate()
 
 
+def test_param_cache_relpos_grouped_refresh(ops):
+    """The expanded relative-position biases of several window-attention modules (different window sizes / head counts) live in the
+    parameter cache: made once, re-expanded in place for ALL of them by one grouped launch in refresh() (next to the batched cast of
+    the weights), re-made lazily when a table changed without a refresh."""
+    from uenc import kernels as K
+    ops.CACHE.invalidate()
+    tabs = [(torch.nn.Parameter(torch.randn((2 * ws - 1) ** 2, nH, device="cuda") * 0.5), ws) for ws, nH in ((12, 6), (12, 24), (7, 3), (5, 2))]
+    w = _p(64, 128, seed=5)                                       # a weight next to them: both kinds are refreshed in the same call
+    first = [ops.CACHE.relpos(t, ws) for t, ws in tabs]
+    m0 = ops.CACHE.mat(w)
+    for (t, ws), got in zip(tabs, first):
+        assert torch.equal(got, K.relpos_expand(t.detach(), ws)[0])
+    for step in range(2):
+        with torch.no_grad():
+            for t, _ in tabs:
+                t.mul_(1.25).add_(0.1)
+            w.add_(1.0)
+        ops.CACHE.refresh()
+        for (t, ws), old in zip(tabs, first):
+            got = ops.CACHE.relpos(t, ws)
+            assert got.data_ptr() == old.data_ptr()                # refreshed in place
+            assert torch.equal(got, K.relpos_expand(t.detach(), ws)[0])
+        assert torch.equal(ops.CACHE.mat(w), w.detach().to(torch.bfloat16)) and ops.CACHE.mat(w).data_ptr() == m0.data_ptr()
+    with torch.no_grad():
+        tabs[1][0].add_(1.0)                                       # no refresh: the version check re-makes it
+    assert torch.equal(ops.CACHE.relpos(*tabs[1]), K.relpos_expand(tabs[1][0].detach(), 12)[0])
+    ops.CACHE.invalidate()
+
+
 def test_wgrad_queue_grouped_launch(ops):
     """Deferred, grouped weight gradients == the immediate per-GEMM path (both tile classes, ragged N / K, several
     token-range splits, accumulation into existing .grad, bias sums)."""

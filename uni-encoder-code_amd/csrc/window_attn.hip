@@ -735,6 +735,45 @@ __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __r
     }
 }
 
+// Grouped form: the expanded biases of MANY attention modules in one launch (24 per step for Swin-L, ~9 us each alone for 1-4 MB of
+// stores: the launches, not the bytes, were the cost).  table: n descriptors in device memory, 40 bytes each:
+// { const float* table; float* bias_q; float* bias_k (may be NULL: not written); int nH, ws, NP, blk_begin; }, blk_begin = exclusive
+// prefix sum of ceil(nH * NP * NP / 2048); total_blocks = the full sum.
+struct RelposDesc { const float* table; float* bias_q; float* bias_k; int nH, ws, NP, blk_begin; };
+__global__ __launch_bounds__(256) void relpos_expand_grouped_kernel(const RelposDesc* __restrict__ tab, int n) {
+    int lo = 0, hi = n - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].blk_begin <= blk) lo = mid; else hi = mid - 1;
+    }
+    const RelposDesc d = tab[lo];
+    const int ws = d.ws, NP = d.NP, N = ws * ws, T1 = 2 * ws - 1;
+    const long total = (long)d.nH * NP * NP;
+    const long base = (long)(blk - d.blk_begin) * 2048;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long i = base + j * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int key = (int)(i % NP), q = (int)((i / NP) % NP), h = (int)(i / ((long)NP * NP));
+        float v = 0.f;
+        if (key >= N) v = -30000.0f;
+        else if (q < N) {
+            const int qy = q / ws, qx = q % ws, ky = key / ws, kx = key % ws;
+            v = LOG2E * d.table[((qy - ky + ws - 1) * T1 + (qx - kx + ws - 1)) * d.nH + h];
+        }
+        d.bias_q[i] = v;
+        if (d.bias_k != nullptr) d.bias_k[((long)h * NP + key) * NP + q] = v;
+    }
+}
+
+extern "C" int uenc_relpos_expand_grouped(const void* table, int n, int total_blocks, hipStream_t stream) {
+    UENC_CHECK_ARG(table && n > 0 && total_blocks > 0 && ((uintptr_t)table & 7) == 0);
+    static_assert(sizeof(RelposDesc) == 40, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(relpos_expand_grouped_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, (const RelposDesc*)table, n);
+    UENC_LAUNCH_RET();
+}
+
 static int wattn_ntiles(int ws) { return (ws * ws + 15) / 16; }
 
 extern "C" int uenc_window_attn_np(int ws) { return wattn_ntiles(ws) * 16; }

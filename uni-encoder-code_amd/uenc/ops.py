@@ -120,6 +120,16 @@ class ParamCache:
     def vec16(self, p: torch.Tensor) -> torch.Tensor:
         return self._get(p, "v", lambda: K.cast_bf16(p.detach().contiguous()), None if K.EXACT else (0, 1, p.numel(), 0))
 
+    def relpos(self, table: torch.Tensor, ws: int) -> torch.Tensor:
+        """Expanded relative-position bias (nH, NP, NP) fp32 of a window-attention module (the kernels' `bias_q`; query-major, scaled by
+        log2(e)), kept while the table is unchanged; `refresh()` re-expands the biases of ALL modules with one grouped launch (24
+        launches of ~9 us per Swin-L step otherwise).  Verification mode: the fp32 kernels index the table themselves."""
+        if K.EXACT:
+            return table.detach()
+        ok = table.dtype == F32 and table.is_contiguous()
+        return self._get(table, ("relpos", ws), lambda: K.relpos_expand(table.detach().contiguous(), ws)[0],
+                         ("relpos", ws, table.shape[1]) if ok else None)
+
     def refresh(self):
         """Re-cast every cached operand copy from its (updated) fp32 master, in one launch."""
         import numpy as np
@@ -136,7 +146,13 @@ class ParamCache:
             return
         if self._table is None:
             pieces, keys, dev = [], [], None
+            rel = []                                            # (table ptr, bias ptr, nH, ws, NP) of the expanded relative-position biases
             for k, e in self._store.items():
+                if isinstance(e[4], tuple) and e[4] and e[4][0] == "relpos":
+                    rel.append((e[1], e[2].data_ptr(), e[4][2], e[4][1], e[2].shape[-1]))
+                    keys.append(k)
+                    dev = e[2].device
+                    continue
                 if isinstance(e[4], list):                      # an operand stacked from two masters: one piece per master
                     for src, doff, rows, cols, tr in e[4]:
                         pieces.append((src, e[2].data_ptr() + 2 * doff, rows, cols, tr))
@@ -151,11 +167,22 @@ class ParamCache:
             for i, (src, dst, rows, cols, tr) in enumerate(pieces):
                 desc[i] = (src, dst, rows, cols, tr, -(-cols // 64), tb)
                 tb += -(-rows // 64) * -(-cols // 64)
-            tab = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+            tab = torch.from_numpy(desc.view(np.uint8).copy()).to(dev) if len(pieces) else None
+            rtab, rblocks = None, 0
+            if rel:
+                rdesc = np.zeros(len(rel), dtype=[("table", "<u8"), ("bias_q", "<u8"), ("bias_k", "<u8"), ("nH", "<i4"), ("ws", "<i4"),
+                                                  ("NP", "<i4"), ("blk_begin", "<i4")])
+                for i, (tp, bp, nH, ws, NP) in enumerate(rel):
+                    rdesc[i] = (tp, bp, 0, nH, ws, NP, rblocks)
+                    rblocks += -(-(nH * NP * NP) // 2048)
+                rtab = torch.from_numpy(rdesc.view(np.uint8).copy()).to(dev)
             keys = (keys, len(pieces))
-            self._table = (tab, keys[1], tb, keys[0])
-        tab, n, total, keys = self._table
-        check(lib.uenc_cast_multi(tab.data_ptr(), n, total, stream_ptr()), "cast_multi")
+            self._table = (tab, keys[1], tb, keys[0], rtab, len(rel), rblocks)
+        tab, n, total, keys, rtab, rn, rblocks = self._table
+        if n:
+            check(lib.uenc_cast_multi(tab.data_ptr(), n, total, stream_ptr()), "cast_multi")
+        if rn:
+            check(lib.uenc_relpos_expand_grouped(rtab.data_ptr(), rn, rblocks, stream_ptr()), "relpos_expand_grouped")
         for k in keys:
             e = self._store[k]
             if len(e) > 5:
@@ -845,7 +872,7 @@ class SwinBlockFn(torch.autograd.Function):
             x2 = x2.contiguous()
         xn, _, st1 = K.layernorm_fwd(x2, g1.detach(), b1.detach(), out_dtype=BF16)
         qkv = K.gemm_nt(xn, CACHE.mat(wqkv), bias=bqkv.detach())
-        bias_q, bias_k = K.relpos_expand(table.detach().contiguous(), ws)
+        bias_q = bias_k = CACHE.relpos(table, ws)         # (the kernels read bias_q only; refreshed for all blocks by one launch per step)
         attn = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, ws, shift, scale)
         x1 = _branch_gemm(attn.view(M, C), CACHE.mat(wproj), bproj.detach(), x2, C, s1)
         xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
