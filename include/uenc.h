@@ -225,7 +225,10 @@ int uenc_relpos_expand(const float* table /* ((2ws-1)^2, nH) */, float* bias_q /
  * the table's version: uenc.ops.ParamCache.relpos).  (The window-attention kernels do not read bias_k any more: it may alias
  * bias_q in their calls.) */
 int uenc_relpos_expand_grouped(const void* table, int n, int total_blocks, uenc_stream_t stream);
-int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
+/* lse (B,H,W,nH) fp32 or NULL: the softmax row statistics max + log2(sum) of every real token and head (scores in log2 units), written
+ * by the forward; given back to uenc_window_attn_bwd, the 12 x 12 backward computes the probabilities from them instead of repeating
+ * the maximum / sum passes (other window sizes, and lse == NULL, recompute). */
+int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, float* lse, int B, int H, int W,
                          int C, int nH, int ws, int shift, float scale, uenc_stream_t stream);
 /* dqkv (B,H,W,3C) bf16 written.  dS_ws: scratch of uenc_window_attn_bwd_ws_floats() floats (dense per-workgroup sums of
  * dS, overwritten).  The two parameter gradients are ACCUMULATED (+=, float atomics) straight into the caller's buffers, i.e.
@@ -234,7 +237,8 @@ int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bia
  * F.pad appends after norm1, swin.py:254, whose q/k/v equal the bias). */
 long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int ws);
 int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                         const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
+                         const void* o_saved, const float* lse /* of uenc_window_attn_fwd, or NULL */, const void* d_out, void* dqkv,
+                         float* dS_ws, float* dtable, float* dbias_pad,
                          int B, int H, int W, int C, int nH, int ws, int shift, float scale, int defer_dtable, uenc_stream_t stream);
 /* defer_dtable != 0: dqkv and dbias_pad as above, but the relative-position-table gradient is NOT reduced: dS_ws keeps the dense partials
  * [nH][G][ntiles][NP * 16] (G = uenc_window_attn_bwd_groups(...), ntiles = NP / 16) and the caller, keeping dS_ws untouched, reduces the

@@ -198,6 +198,14 @@ def test_window_attention_fwd_bwd(K, ws, H, W, nH, shift):
     _close(dqkv.view(B, H * W, 3 * C), q32.grad, 3e-2 * gs, 3e-2)
     _close(dtab - dtab0, t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
     _close(dpad - dpad0, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)
+    # the same with the forward's saved row statistics (12 x 12 windows: the backward skips its maximum / sum passes; others ignore them)
+    out2, lse = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), qb, bq, ws, shift, 32 ** -0.5, want_lse=True)
+    assert torch.equal(out2, out) and lse.shape == (B, H, W, nH) and bool(torch.isfinite(lse).all())
+    dtab, dpad = dtab0.clone(), dpad0.clone()
+    dqkv = K.window_attn_bwd(qkv.view(B, H, W, 3 * C), qb, bq, bk, out, do.view(B, H, W, C), ws, shift, 32 ** -0.5, dtable=dtab, dbias=dpad, lse=lse)
+    _close(dqkv.view(B, H * W, 3 * C), q32.grad, 3e-2 * gs, 3e-2)
+    _close(dtab - dtab0, t32.grad, 3e-2 * float(t32.grad.abs().max()) + 1e-3, 3e-2)
+    _close(dpad - dpad0, b32.grad, 3e-2 * float(b32.grad.abs().max()) + 1e-3, 3e-2)
 
 
 @pytest.mark.parametrize("H,W,nH,shift", [(96, 120, 6, 6), (40, 50, 24, 0)])

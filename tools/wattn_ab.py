@@ -22,15 +22,15 @@ for (H, W, C, tag) in [(256, 512, 192, "s1"), (128, 256, 384, "s2"), (64, 128, 7
     bq, bk = K.relpos_expand(table, ws)
     do = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
     for shift in (0, 6):
-        out = K.window_attn_fwd(qkv, qb, bq, ws, shift, 32 ** -0.5)
+        out, lse = K.window_attn_fwd(qkv, qb, bq, ws, shift, 32 ** -0.5, want_lse=True)
         row, ref = [], None
         for v in variants:
             os.environ["UENC_WATTN_VARIANT"] = str(v)
-            got = K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, shift, 32 ** -0.5)
+            got = K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, shift, 32 ** -0.5, lse=lse)
             got = got[0] if isinstance(got, (tuple, list)) else got
             got = got.clone()
             same = True if ref is None else bool(torch.equal(ref, got))
             ref = got if ref is None else ref
-            row.append((v, timeit(lambda: K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, shift, 32 ** -0.5)), same))
+            row.append((v, timeit(lambda: K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, shift, 32 ** -0.5, lse=lse)), same))
         print(f"{tag} shift {shift}: " + "   ".join(f"variant {v}: {t:8.1f} us (dqkv identical {s})" for v, t, s in row), flush=True)
 os.environ["UENC_WATTN_VARIANT"] = "0"

@@ -40,6 +40,8 @@ struct WAttn {
     const float* bias_q;    // (nH, NP, NP) [h][q][key]  log2(e) * relative-position bias, -30000 for key >= N
     const float* bias_k;    // (nH, NP, NP) [h][key][q]  same, key-major (backward phase B)
     bf16* out;              // (B, H, W, C) attention output (before proj)
+    float* lse;             // (B, H, W, nH) fp32 or NULL: log2-domain row statistics max + log2(sum) of the softmax -- written by the forward,
+                            // read by the 12 x 12 backward (which then needs no max / sum passes); NULL: the backward recomputes them
     // backward only
     const bf16* o_saved;    // forward output
     const bf16* d_out;      // (B, H, W, C)
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
     sum = xor16_sum(sum);
     sum = xor32_sum(sum);
     const float inv = 1.0f / sum;
+    if (p.lse != nullptr && fg == 0 && qtok >= 0) p.lse[(long)qtok * p.nH + head] = mx + __builtin_amdgcn_logf(sum);     // v_log_f32 = log2
 
     f32x4 o[2] = {zero4, zero4};
 #pragma unroll
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(64 * NTILES) void wattn_fwd_kernel(WAttn p) {
 //     it is summed over the workgroup's windows in registers and written once as a dense [q][key] partial;
 //     wattn_dtable_kernel then sums the partials over g and along the diagonals (q - key = const) into the table gradient.
 __device__ __attribute__((aligned(16))) unsigned int g_wattn_zero16[4];      // a 16-byte chunk of zeros (rows beyond N, dO pad rows)
+__device__ float g_wattn_big = 1e30f;                                        // "row statistic" of a slot without a token: exp2(s - 1e30) = 0
 
 //   * LDSB (12 x 12 windows): the relative-position bias of phase A is looked up in a 529-entry LDS copy of the head's table
 //     instead of being loaded as dense [q][key] rows from L2 (83 KB per window-head, more than its q / k / v / dO): an ordinary
@@ -269,9 +273,13 @@ __device__ __attribute__((aligned(16))) unsigned int g_wattn_zero16[4];      // 
 //     result stores.  The loader takes part in the three barriers of a window: stage landed (its vmcnt(0)) -> top barrier -> slots +
 //     DMA of the NEXT window into the other stage (free since the previous end barrier) -> mid barrier (the slots become visible:
 //     the compute waves prefetch their next saved-output rows) -> end barrier.
-template <int NTILES, bool LDSB, bool LOADER>
+//   * LSE (with LOADER): the forward saved the row statistics; the loader brings the 144 values of a window by three 4-byte-per-lane
+//     LDS-DMA instructions and phase A computes P = exp2(s - lse) directly: no running maximum, no sum, no reciprocal, no cross-lane
+//     butterflies (about a quarter of phase A's VALU instructions; the phases' time follows their VALU count).
+template <int NTILES, bool LDSB, bool LOADER, bool LSE = false>
 __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_kernel(WAttn p, int G) {
     static_assert(!LDSB || NTILES == 9, "the LDS bias table is laid out for ws = 12 (N = NP = 144, key quads never straddle a window row)");
+    static_assert(!LSE || LOADER, "the saved row statistics come in through the loader wave");
     using Cf = WCfg<NTILES>;
     constexpr int NWAVES = NTILES + (LOADER ? 1 : 0), NTH = 64 * NWAVES;
     constexpr int NP = Cf::NP, NKB = Cf::NKB, NK2 = Cf::NK2;
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     constexpr int OFF_P = OFF_PAD + 96 * 4;            // bf16 P[key tile][NK2 query rows][16 keys]: the softmax of phase A, read back
     constexpr int PSUB = NK2 * 32;                     //   transposed (ds_read_b64_tr_b16) as the P / dS operand tiles of phase B
     constexpr int OFF_BT = OFF_P + NTILES * PSUB;      // LDSB: float rev[532], rev[528 - t] = log2(e) * table[t][head]
+    constexpr int OFF_LSE = OFF_BT + 532 * 4;          // LSE: float lse_s[2 stages][192]: the saved row statistics of the window's queries
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* delta = (float*)(smem + OFF_DEL);
     float* padacc = (float*)(smem + OFF_PAD);          // [3][32] q|k|v bias gradient from padding slots, summed over this WG's windows
@@ -328,6 +337,15 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                     if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : (img == 3 ? p.d_out : p.o_saved) + (long)t * C) + hoff + chunk * 8;
                     else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
                     __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
+                }
+            }
+            if constexpr (LSE) {                       // one float per query slot: 64 slots (256 B) per instruction; padding slots get +inf-like (P = 0)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int row = j * 64 + lane;
+                    const int t = row < NK2 ? tok[row] : -2;
+                    const float* src = t >= 0 ? p.lse + (long)t * p.nH + head : &g_wattn_big;
+                    __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + OFF_LSE + (st * 192 + j * 64) * 4), 4, 0, 0);
                 }
             }
         } else {
@@ -465,7 +483,7 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
             dl = xor32_sum(dl);
             f32x4 s[NTILES];
             const int ridq = rid[qi];
-            float mx = -1e30f;
+            float mx = LSE ? ((const float*)(smem + OFF_LSE))[st * 192 + qi] : -1e30f;      // LSE: the saved max + log2(sum) takes the maximum's place
 #pragma unroll
             for (int k3 = 0; k3 < NTILES; k3 += 3) {
                 float4 bcur[3];
@@ -497,13 +515,15 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                             for (int r = 0; r < 4; ++r)
                                 if ((int)((rk >> (8 * r)) & 0xffu) != ridq) s[kt][r] -= 100.0f * LOG2E;
                         }
-                        mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+                        if (!LSE) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);     // bound the loads hoisted ahead (register pressure)
             }
-            mx = xor16_max(mx);
-            mx = xor32_max(mx);
+            if (!LSE) {
+                mx = xor16_max(mx);
+                mx = xor32_max(mx);
+            }
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NTILES; ++kt)
@@ -513,9 +533,12 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                     s[kt][r] = e;
                     sum += e;
                 }
-            sum = xor16_sum(sum);
-            sum = xor32_sum(sum);
-            const float inv = 1.0f / sum;
+            float inv = 1.0f;                              // LSE: the exponentials above are the probabilities already
+            if (!LSE) {
+                sum = xor16_sum(sum);
+                sum = xor32_sum(sum);
+                inv = 1.0f / sum;
+            }
             if (fg == 0) delta[qi] = dl;
             __builtin_amdgcn_sched_barrier(0);
             const float qreal = qi < p.N ? 1.f : 0.f;
@@ -800,7 +823,7 @@ static int fill_params(WAttn& p, const void* qkv, const void* qkv_bias, const fl
     p.nWw = p.Wp / ws; p.nWin = (p.Hp / ws) * p.nWw; p.nWinTotal = B * p.nWin; p.N = ws * ws;
     p.scale = scale;
     { const char* e = getenv("UENC_WATTN_VARIANT"); p.variant = e ? atoi(e) : 0; }
-    p.out = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab_ws = nullptr; p.dpad = nullptr;
+    p.out = nullptr; p.lse = nullptr; p.o_saved = nullptr; p.d_out = nullptr; p.dqkv = nullptr; p.dtab_ws = nullptr; p.dpad = nullptr;
     return UENC_OK;
 }
 
@@ -837,13 +860,17 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
             e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_loader);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shm_loader + 1536));
         }
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
-    if (HAS_LDSB && !(p.variant & 6))                  // 12 x 12 windows: LDS bias table, loader wave
+    if (HAS_LDSB && !(p.variant & 14) && p.lse != nullptr)      // 12 x 12 windows: LDS bias table, loader wave, saved row statistics
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm_loader + 1536, stream, p, G);
+    else if (HAS_LDSB && !(p.variant & 6))             // no statistics given, or bit 3 of UENC_WATTN_VARIANT: recomputed (A/B)
         hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm_loader, stream, p, G);
     else if (HAS_LDSB && !(p.variant & 2))             // bit 2 of UENC_WATTN_VARIANT: every wave issues its share of the DMA (A/B)
         hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, false>), dim3(grid), dim3(64 * NT), shm, stream, p, G);
@@ -869,13 +896,14 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
         default: return UENC_EINVAL;              \
     }
 
-extern "C" int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, int B, int H, int W,
+extern "C" int uenc_window_attn_fwd(const void* qkv, const void* qkv_bias, const float* bias_q, void* out, float* lse, int B, int H, int W,
                                     int C, int nH, int ws, int shift, float scale, hipStream_t stream) {
     WAttn p;
     int rc = fill_params(p, qkv, qkv_bias, bias_q, bias_q, B, H, W, C, nH, ws, shift, scale);
     if (rc != UENC_OK) return rc;
     UENC_CHECK_ARG(out != nullptr);
     p.out = (bf16*)out;
+    p.lse = lse;
 #define CALL(NT) launch_fwd<NT>(p, stream)
     WATTN_DISPATCH(wattn_ntiles(ws), CALL)
 #undef CALL
@@ -901,7 +929,7 @@ extern "C" long uenc_window_attn_bwd_ws_floats(int B, int H, int W, int nH, int 
 // the q | k | v (3C) slice of the qkv-bias gradient that flows through padding slots.  dS_ws: scratch of
 // uenc_window_attn_bwd_ws_floats() floats.
 extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const float* bias_q, const float* bias_k,
-                                    const void* o_saved, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
+                                    const void* o_saved, const float* lse, const void* d_out, void* dqkv, float* dS_ws, float* dtable, float* dbias_pad,
                                     int B, int H, int W, int C, int nH, int ws, int shift, float scale, int defer_dtable, hipStream_t stream) {
     WAttn p;
     int rc = fill_params(p, qkv, qkv_bias, bias_q, bias_k, B, H, W, C, nH, ws, shift, scale);
@@ -909,6 +937,7 @@ extern "C" int uenc_window_attn_bwd(const void* qkv, const void* qkv_bias, const
     UENC_CHECK_ARG(bias_k && o_saved && d_out && dqkv && dS_ws && dtable && dbias_pad);
     UENC_CHECK_ARG((((uintptr_t)o_saved | (uintptr_t)d_out | (uintptr_t)dqkv | (uintptr_t)dS_ws) & 15) == 0);
     p.o_saved = (const bf16*)o_saved; p.d_out = (const bf16*)d_out; p.dqkv = (bf16*)dqkv; p.dtab_ws = dS_ws;
+    p.lse = const_cast<float*>(lse);
     p.dpad = dbias_pad;
 #define CALL(NT) { rc = launch_bwd<NT>(p, dtable, defer_dtable, stream); if (rc != UENC_OK) return rc; }
     WATTN_DISPATCH(wattn_ntiles(ws), CALL)

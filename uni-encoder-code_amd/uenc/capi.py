@@ -70,7 +70,7 @@ _SIGNATURES = {
     "uenc_window_attn_np": [c_i],
     "uenc_relpos_expand": [c_p, c_p, c_p, c_i, c_i, c_p],
     "uenc_relpos_expand_grouped": [c_p, c_i, c_i, c_p],
-    "uenc_window_attn_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "uenc_window_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "uenc_postproc_semantic": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_postproc_panoptic_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "uenc_postproc_panoptic_label": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -89,7 +89,7 @@ _SIGNATURES = {
     "uenc_mha_f32_fwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
     "uenc_mha_f32_bwd": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_l,
                          c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_u, c_p],
-    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
+    "uenc_window_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
 }
 
 

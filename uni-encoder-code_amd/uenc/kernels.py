@@ -491,8 +491,9 @@ def relpos_expand(table: torch.Tensor, ws: int):
 
 
 def window_attn_fwd(qkv: torch.Tensor, qkv_bias16: torch.Tensor, bias_q: torch.Tensor, ws: int, shift: int,
-                    scale: float) -> torch.Tensor:
-    """qkv (B, H, W, 3C) bf16 -> attention output (B, H, W, C) bf16 (before proj).  head_dim is 32."""
+                    scale: float, want_lse: bool = False):
+    """qkv (B, H, W, 3C) bf16 -> attention output (B, H, W, C) bf16 (before proj).  head_dim is 32.
+    want_lse: also return the softmax row statistics (B, H, W, nH) fp32 (max + log2 sum, log2 units) for window_attn_bwd(lse=...)."""
     B, H, W, C3 = qkv.shape
     C = C3 // 3
     if EXACT:                                   # qkv / bias fp32, bias_q = the raw relative-position table ((2ws-1)^2, nH)
@@ -501,13 +502,14 @@ def window_attn_fwd(qkv: torch.Tensor, qkv_bias16: torch.Tensor, bias_q: torch.T
         out = torch.empty((B, H, W, C), dtype=torch.float32, device=qkv.device)
         check(lib.uenc_window_attn_f32_fwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), out.data_ptr(), B, H, W, C, C // 32, ws,
                                            shift, float(scale), stream_ptr()), "window_attn_f32_fwd")
-        return out
+        return (out, None) if want_lse else out
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv_bias16.dtype == torch.bfloat16
     assert qkv_bias16.numel() == C3 and C % 32 == 0 and bias_q.shape[0] == C // 32
     out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=qkv.device)
-    check(lib.uenc_window_attn_fwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), out.data_ptr(), B, H, W, C,
-                                   C // 32, ws, shift, float(scale), stream_ptr()), "window_attn_fwd")
-    return out
+    lse = torch.empty((B, H, W, C // 32), dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(lib.uenc_window_attn_fwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), out.data_ptr(), lse.data_ptr() if want_lse else 0,
+                                   B, H, W, C, C // 32, ws, shift, float(scale), stream_ptr()), "window_attn_fwd")
+    return (out, lse) if want_lse else out
 
 
 _SCRATCH = {}
@@ -525,7 +527,8 @@ def _scratch(tag: str, nbytes: int, device) -> torch.Tensor:
 
 
 def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, shift: int, scale: float,
-                    dtable: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, defer: Optional[SmallReductions] = None):
+                    dtable: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, defer: Optional[SmallReductions] = None,
+                    lse: Optional[torch.Tensor] = None):
     """-> dqkv (B,H,W,3C).  The two parameter gradients are ACCUMULATED by the kernels into `dtable` ((2ws-1)^2, nH) fp32 -- the
     relative-position table's .grad -- and `dbias` (3C) fp32 -- the share of qkv.bias.grad that flows through padding slots; when
     a buffer is not given (no training) the contribution goes to scratch."""
@@ -555,8 +558,11 @@ def window_attn_bwd(qkv, qkv_bias16, bias_q, bias_k, o_saved, d_out, ws: int, sh
         defer.add_dtable(wsbuf, dtable, int(lib.uenc_window_attn_bwd_groups(B, H, W, nH, ws)), nH, ws, int(lib.uenc_window_attn_np(ws)) // 16)
     else:
         wsbuf = _scratch("wattn_dS", nws * 4, qkv.device)                # dense dS partials (internal)
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, H, W, nH)
     check(lib.uenc_window_attn_bwd(qkv.data_ptr(), qkv_bias16.data_ptr(), bias_q.data_ptr(), bias_k.data_ptr(),
-                                   o_saved.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(), dtable.data_ptr(), dbias.data_ptr(),
+                                   o_saved.data_ptr(), lse.data_ptr() if lse is not None else 0, d_out.data_ptr(), dqkv.data_ptr(), wsbuf.data_ptr(),
+                                   dtable.data_ptr(), dbias.data_ptr(),
                                    B, H, W, C, nH, ws, shift, float(scale), int(defer is not None), stream_ptr()), "window_attn_bwd")
     return dqkv
 

@@ -873,7 +873,11 @@ class SwinBlockFn(torch.autograd.Function):
         xn, _, st1 = K.layernorm_fwd(x2, g1.detach(), b1.detach(), out_dtype=BF16)
         qkv = K.gemm_nt(xn, CACHE.mat(wqkv), bias=bqkv.detach())
         bias_q = bias_k = CACHE.relpos(table, ws)         # (the kernels read bias_q only; refreshed for all blocks by one launch per step)
-        attn = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, ws, shift, scale)
+        # the softmax row statistics are kept for the backward of 12 x 12 windows (its kernel then skips the maximum / sum passes)
+        want_lse = ws == 12 and not K.EXACT and any(ctx.needs_input_grad)
+        attn = K.window_attn_fwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, ws, shift, scale, want_lse=want_lse)
+        attn, lse = attn if want_lse else (attn, None)
+        ctx.has_lse = lse is not None
         x1 = _branch_gemm(attn.view(M, C), CACHE.mat(wproj), bproj.detach(), x2, C, s1)
         xn2, _, st2 = K.layernorm_fwd(x1, g2.detach(), b2.detach(), out_dtype=BF16)
         pre = torch.empty((M, w1.shape[0]), dtype=K.adt(), device=x.device)
@@ -881,14 +885,15 @@ class SwinBlockFn(torch.autograd.Function):
         x2o = _branch_gemm(h, CACHE.mat(w2), bb2.detach(), x1, C, s2)
         ctx.dp = (s1, s2)
         ctx.save_for_backward(x2, st1, xn, qkv, bias_q, bias_k, attn, x1, st2, xn2, pre, h,
-                              g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2)
+                              g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2, *([lse] if lse is not None else []))
         ctx.geom = (B, L, C, H, W, ws, shift, nH, scale)
         return x2o.view(B, L, C)
 
     @staticmethod
     def backward(ctx, dxo):
         (x2, st1, xn, qkv, bias_q, bias_k, attn, x1, st2, xn2, pre, h,
-         g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2) = ctx.saved_tensors
+         g1, b1, wqkv, bqkv, table, wproj, bproj, g2, b2, w1, bb1, w2, bb2) = ctx.saved_tensors[:25]
+        lse = ctx.saved_tensors[25] if ctx.has_lse else None
         B, L, C, H, W, ws, shift, nH, scale = ctx.geom
         M = B * L
         d2 = dxo.reshape(M, C)
@@ -921,7 +926,7 @@ class SwinBlockFn(torch.autograd.Function):
             _branch_wgrad(dx1h, attn.view(M, C), grad_buf(wproj), grad_buf(bproj), (wproj, bproj), s1)
         # (the kernels add the relative-position-table gradient and the padding-slot share of the qkv-bias gradient straight into .grad)
         dqkv = _wattn_bwd(qkv.view(B, H, W, 3 * C), CACHE.vec16(bqkv), bias_q, bias_k, attn, dattn.view(B, H, W, C), ws, shift, scale,
-                                 dtable=grad_buf(table) if train else None, dbias=grad_buf(bqkv) if train else None)
+                                 dtable=grad_buf(table) if train else None, dbias=grad_buf(bqkv) if train else None, lse=lse)
         dqkv2 = dqkv.view(M, 3 * C)
         dxn = K.gemm_nt(dqkv2, CACHE.mat_t(wqkv))
         if train:
