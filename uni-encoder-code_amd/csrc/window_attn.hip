@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     }
     if (head >= p.nH || g >= G) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fg = lane >> 4;
-    const int C = p.C, hoff = head * 32;
+    const int C = p.C, hoff = head * 32, C3i = 3 * p.C;
     const long C3 = 3 * (long)p.C;
     const float sc = p.scale * LOG2E;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -326,17 +326,36 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     auto issue = [&](int st, int tb) {                 // st: stage, tb: slot buffer
         const int* tok = (const int*)(smem + OFF_TOK) + tb * NK2;
         constexpr int PER_IMG = NK2 / 16;
-        if constexpr (LOADER) {                        // the loader wave: all four images of a 16-row block from one slot read
-#pragma unroll 2
-            for (int rb = 0; rb < PER_IMG; ++rb) {
+        if constexpr (LOADER) {
+            // The loader wave: all five images of a 16-row block from one slot read.  Sources are a UNIFORM base per image plus a 32-bit
+            // byte offset per lane (scalar-base addressing: no 64-bit address arithmetic per instruction), token rows and padding slots
+            // as two exec-masked instruction groups (the second one is skipped by all but the windows on the map's edges); the rows
+            // beyond the window's 144 slots were zeroed once at kernel start and are never written.  ~6 instructions per DMA instead
+            // of ~25: the issue of a window's 45 DMAs took 8.3 k cycles before, longer than phase A.
+            const char* bq = (const char*)(p.qkv + hoff);
+            const char* bdo = (const char*)(p.d_out + hoff);
+            const char* bo = (const char*)(p.o_saved + hoff);
+            const char* bpad = (const char*)(p.qkv_bias + hoff);
+            unsigned char* stage = smem + st * STAGE;
+#pragma unroll 3
+            for (int rb = 0; rb < NP / 16; ++rb) {
                 const int row = rb * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 1) & 3);
                 const int t = tok[row];
-#pragma unroll
-                for (int img = 0; img < 5; ++img) {
-                    const bf16* src = (const bf16*)g_wattn_zero16;
-                    if (t >= 0) src = (img < 3 ? p.qkv + (long)t * C3 + img * C : (img == 3 ? p.d_out : p.o_saved) + (long)t * C) + hoff + chunk * 8;
-                    else if (t == -1 && img < 3) src = p.qkv_bias + img * C + hoff + chunk * 8;
-                    __builtin_amdgcn_global_load_lds(src, (lds_void*)(smem + st * STAGE + img * IMG + rb * 1024), 16, 0, 0);
+                unsigned char* d0 = stage + rb * 1024;
+                if (t >= 0) {
+                    const unsigned o3 = ((unsigned)(t * C3i) + chunk * 8) * 2u, o1 = ((unsigned)(t * C) + chunk * 8) * 2u;
+                    __builtin_amdgcn_global_load_lds(bq + o3, (lds_void*)(d0), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bq + 2 * C + o3, (lds_void*)(d0 + IMG), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bq + 4 * C + o3, (lds_void*)(d0 + 2 * IMG), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bdo + o1, (lds_void*)(d0 + 3 * IMG), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bo + o1, (lds_void*)(d0 + 4 * IMG), 16, 0, 0);
+                } else {                               // padding slot (t == -1; slots beyond N do not occur for 12 x 12): q, k, v = the qkv bias, dO = O = 0
+                    const unsigned oc = chunk * 16u;
+                    __builtin_amdgcn_global_load_lds(bpad + oc, (lds_void*)(d0), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bpad + 2 * C + oc, (lds_void*)(d0 + IMG), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bpad + 4 * C + oc, (lds_void*)(d0 + 2 * IMG), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const char*)g_wattn_zero16, (lds_void*)(d0 + 3 * IMG), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const char*)g_wattn_zero16, (lds_void*)(d0 + 4 * IMG), 16, 0, 0);
                 }
             }
             if constexpr (LSE) {                       // one float per query slot: 64 slots (256 B) per instruction; padding slots get +inf-like (P = 0)
@@ -383,6 +402,11 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     for (int kt = 0; kt < NTILES; ++kt) dsacc[kt] = zero4;
     for (int t = threadIdx.x; t < 96; t += NTH) padacc[t] = 0.f;
     for (int t = threadIdx.x; t < NTILES * PSUB / 16; t += NTH) ((u32x4*)Pimg)[t] = (u32x4){0u, 0u, 0u, 0u};     // rows >= NP are never written
+    if constexpr (LOADER) {                            // rows NP .. NK2 - 1 of every staged image: zero for good (the loader writes rows < NP only)
+        constexpr int TAIL = (NK2 - NP) * 4;           // 16-byte chunks per image
+        for (int t = threadIdx.x; t < 2 * NIMG * TAIL; t += NTH)
+            *(u32x4*)(smem + (t / TAIL) * IMG + NP * 64 + (t % TAIL) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
 
     int win = g;
     bf16x8 o_next;                                     // saved forward output row of this lane's query, next window
