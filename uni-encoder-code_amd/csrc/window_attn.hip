@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     constexpr int PSUB = NK2 * 32;                     //   transposed (ds_read_b64_tr_b16) as the P / dS operand tiles of phase B
     constexpr int OFF_BT = OFF_P + NTILES * PSUB;      // LDSB: float rev[532], rev[528 - t] = log2(e) * table[t][head]
     constexpr int OFF_LSE = OFF_BT + 532 * 4;          // LSE: float lse_s[2 stages][192]: the saved row statistics of the window's queries
+    constexpr int OFF_MF = OFF_LSE + 1536;             // LOADER: int mflag[4]: "this window takes the shift mask", per slot buffer (written with the slots)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* delta = (float*)(smem + OFF_DEL);
     float* padacc = (float*)(smem + OFF_PAD);          // [3][32] q|k|v bias gradient from padding slots, summed over this WG's windows
@@ -319,8 +320,11 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
     auto slots = [&](int win, int st) {                // st: slot buffer
         const int b = win / p.nWin, wrem = win - b * p.nWin;
         const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
-        if (LOADER) window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, 64, lane);
-        else window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
+        if (LOADER) {
+            window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, 64, lane);
+            // the compute waves read the flag instead of repeating the three integer divisions of the window decode (~500 cycles per window)
+            if (lane == 0) ((int*)(smem + OFF_MF))[st] = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
+        } else window_slots<NK2, NTILES == 9>(p, b, wi, wj, (int*)(smem + OFF_TOK) + st * NK2, smem + OFF_RID + st * NK2, nullptr, NTH);
     };
     // LDS-DMA of one window's q, k, v, dO images: 16 rows (1 KB) per wave instruction
     auto issue = [&](int st, int tb) {                 // st: stage, tb: slot buffer
@@ -465,9 +469,14 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
         const int tbuf = LOADER ? it % 3 : st;
         const int* tokoff = (const int*)(smem + OFF_TOK) + tbuf * NK2;
         const unsigned char* rid = smem + OFF_RID + tbuf * NK2;
-        const int b = win / p.nWin, wrem = win - b * p.nWin;
-        const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
-        const bool masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
+        bool masked;
+        if constexpr (LOADER) {
+            masked = __builtin_amdgcn_readfirstlane(((const int*)(smem + OFF_MF))[it % 3]) != 0;
+        } else {
+            const int b = win / p.nWin, wrem = win - b * p.nWin;
+            const int wi = wrem / p.nWw, wj = wrem - wi * p.nWw;
+            masked = p.shift > 0 && (wi == p.Hp / p.ws - 1 || wj == p.nWw - 1);
+        }
         const bool more = win + G < p.nWinTotal;
 
         // bias rows come from L2 in groups of 3 key tiles, one group ahead of their use
@@ -876,7 +885,7 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
     const int G = wattn_bwd_groups(p.nWinTotal, p.nH, NT);
     constexpr size_t shm = ((size_t)2 * 4 * NK2 * 64 + 2 * NK2 * 4 + 2 * NK2 + 15) / 16 * 16 + NK2 * 4 + 96 * 4 + (size_t)NT * NK2 * 32 + 532 * 4;
     constexpr bool HAS_LDSB = NT == 9;
-    constexpr size_t shm_loader = shm + (size_t)2 * NK2 * 64 + NK2 * 4 + NK2 + 16;      // + the fifth image of both stages, the third slot buffer
+    constexpr size_t shm_loader = shm + (size_t)2 * NK2 * 64 + NK2 * 4 + NK2 + 16 + 1536 + 16;      // + the fifth image of both stages, the third slot buffer, the row statistics, the mask flags
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -885,7 +894,7 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_loader);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(shm_loader + 1536));
+                e = hipFuncSetAttribute((const void*)wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB, HAS_LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_loader);
         }
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -893,7 +902,7 @@ static int launch_bwd(const WAttn& p, float* dtab, int defer_dtable, hipStream_t
     const int npair = (p.nH + 1) / 2;
     const unsigned grid = (unsigned)((2 * npair * G + 15) / 16 * 16);
     if (HAS_LDSB && !(p.variant & 14) && p.lse != nullptr)      // 12 x 12 windows: LDS bias table, loader wave, saved row statistics
-        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm_loader + 1536, stream, p, G);
+        hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm_loader, stream, p, G);
     else if (HAS_LDSB && !(p.variant & 6))             // no statistics given, or bit 3 of UENC_WATTN_VARIANT: recomputed (A/B)
         hipLaunchKernelGGL((wattn_bwd_kernel<NT, HAS_LDSB, HAS_LDSB>), dim3(grid), dim3(64 * (NT + 1)), shm_loader, stream, p, G);
     else if (HAS_LDSB && !(p.variant & 2))             // bit 2 of UENC_WATTN_VARIANT: every wave issues its share of the DMA (A/B)
