@@ -244,7 +244,7 @@ def test_full_model_with_dinat_backbone(U):
                   pred_logits=rel(out["pred_logits"], want["pred_logits"]), pred_masks=rel(out["pred_masks"], want["pred_masks"]),
                   loss=float(loss.detach()), loss_oracle=float(wl.detach() if hasattr(wl, "detach") else wl), mask_band=mask_band_figures(out["pred_masks"], want["pred_masks"]))
     assert rel(out["pred_logits"], want["pred_logits"]) < 0.15 and rel(out["pred_masks"], want["pred_masks"]) < 0.15
-    assert abs(float(loss) / float(wl) - 1) < 0.1
+    assert abs(float(loss.detach()) / float(wl.detach()) - 1) < 0.1
     cos = []
     for name, p in m.named_parameters():
         if name.startswith("backbone.") and p.grad is not None and sd[name].grad is not None and p.numel() >= 4096:
