@@ -9,7 +9,7 @@ qb = torch.randn(3 * C, device="cuda").to(torch.bfloat16)
 table = torch.randn((2 * ws - 1) ** 2, nH, device="cuda") * 0.5
 bq, bk = K.relpos_expand(table, ws)
 do = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
-out = K.window_attn_fwd(qkv, qb, bq, ws, 6, 32 ** -0.5)
+out, lse = K.window_attn_fwd(qkv, qb, bq, ws, 6, 32 ** -0.5, want_lse=True)
 for _ in range(6):
-    K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, 6, 32 ** -0.5)
+    K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, 6, 32 ** -0.5, lse=lse)
 torch.cuda.synchronize()
