@@ -20,9 +20,9 @@ for (H, W, C, tag) in [(256, 512, 192, "s1"), (128, 256, 384, "s2"), (64, 128, 7
     bq, bk = K.relpos_expand(table, ws)
     do = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
     for shift in (0, 6):
-        out = K.window_attn_fwd(qkv, qb, bq, ws, shift, 32 ** -0.5)
+        out, lse = K.window_attn_fwd(qkv, qb, bq, ws, shift, 32 ** -0.5, want_lse=True)
         tf = timeit(lambda: K.window_attn_fwd(qkv, qb, bq, ws, shift, 32 ** -0.5))
-        tb = timeit(lambda: K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, shift, 32 ** -0.5))
+        tb = timeit(lambda: K.window_attn_bwd(qkv, qb, bq, bk, out, do, ws, shift, 32 ** -0.5, lse=lse))
         Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
         nwin = B * (Hp // ws) * (Wp // ws) * nH
         gf_f = nwin * 2 * 2 * 144 * 144 * 32 / 1e9

@@ -587,7 +587,10 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
                     s[kt][r] = ds;
                     dsacc[kt][r] += ds * qreal;              // (keys >= N have P = 0 exactly; queries >= N are zeroed here)
                 }
-                *(bf16x4*)(Pimg + kt * PSUB + qi * 32 + fg * 8) = p4;       // key tile kt, row q, keys 4 fg .. 4 fg + 3
+                // key tile kt, row q, keys 4 fg .. 4 fg + 3.  The 8-byte chunk position inside the 32-byte row is XOR-ed with (q >> 2) & 3: the
+                // sixteen lanes of a write (q = 16 w + 0..15, one fg) then cover all 32 banks -- un-swizzled they hit four 32-byte-strided
+                // positions four deep (all of this kernel's SQ_LDS_BANK_CONFLICT cycles, ~8 % of its LDS time)
+                *(bf16x4*)(Pimg + kt * PSUB + qi * 32 + ((fg ^ ((qi >> 2) & 3)) << 3)) = p4;
                 if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
             f32x4 dq[2] = {zero4, zero4};                  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(64 * (NTILES + (LOADER ? 1 : 0))) void wattn_bwd_ke
 #pragma unroll
             for (int qb = 0; qb < NKB; ++qb) {
                 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-                const int prow = 32 * qb + 4 * fg + (fr >> 2), pcol = (fr & 3) * 8;
+                const int prow = 32 * qb + 4 * fg + (fr >> 2), pcol = ((fr & 3) ^ fg) * 8;      // (the row's chunk swizzle: (prow >> 2) & 3 == fg, also for prow + 16)
                 const bf16x4 plo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Psub + prow * 32 + pcol));
                 const bf16x4 phi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Psub + (prow + 16) * 32 + pcol));
                 bf16x8 pb, db;
