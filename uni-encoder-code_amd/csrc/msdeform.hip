@@ -726,12 +726,9 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
     // code: 0 = no record; bit 31 set: bit 30 = slot taken straight from the global counter (hash table full) in bits 0-29,
     // else hash slot << 16 | position within this workgroup's share of the bin
     unsigned code[2][4];
-    const bool runs = !(bn.variant & 8);           // bit 3 of the variant word: one LDS atomic per record (the earlier form, A/B)
-    const int lane64 = tid & 63;
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         const int s = j8 + round * 8;
-        int bin4[4] = {-1, -1, -1, -1};
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) code[round][tp] = 0u;
         if (live && s < LP && bn.variant != 1) {
@@ -746,45 +743,20 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(MsdaP p, MsdaBins bn)
                     // a tap owns the record of its block unless an in-range tap of the same block precedes it
                     const bool dup_y = dy == 1 && t.y0ok && ((t.h0 + 1) / MSDA_BS) == (t.h0 / MSDA_BS);
                     const bool dup_x = dx == 1 && t.x0ok && ((t.w0 + 1) / MSDA_BS) == (t.w0 / MSDA_BS);
-                    if (cy >= 0 && cy < Hl && cx >= 0 && cx < Wl && !dup_y && !dup_x)
-                        bin4[tp] = bm * bn.nblk + bn.boff[l] + (cy / MSDA_BS) * bn.nbx[l] + cx / MSDA_BS;
+                    if (cy >= 0 && cy < Hl && cx >= 0 && cx < Wl && !dup_y && !dup_x) {
+                        const int bin = bm * bn.nblk + bn.boff[l] + (cy / MSDA_BS) * bn.nbx[l] + cx / MSDA_BS;
+                        int h = (int)(((unsigned)bin * 2654435761u) >> 24);
+                        unsigned cd = 0u;
+                        for (int probe = 0; probe < MSDA_HASH; ++probe) {
+                            const int prev = atomicCAS(&h_key[h], -1, bin);
+                            if (prev == -1 || prev == bin) { cd = 0x80000000u | ((unsigned)h << 16) | (unsigned)atomicAdd(&h_cnt[h], 1); break; }
+                            h = (h + 1) & (MSDA_HASH - 1);
+                        }
+                        if (cd == 0u) cd = 0xc0000000u | ((unsigned)atomicAdd(bn.count + (long)bin * MSDA_CNT_STRIDE, 1) & 0x3fffffffu);
+                        code[round][tp] = cd;
+                    }
                 }
             }
-        }
-        // Slot allocation.  The lanes 8 apart in a wave hold the same sample of CONSECUTIVE queries, whose taps mostly fall into the same
-        // 8 x 8 block: a run of such lanes with one bin is allocated by its first lane with ONE pair of LDS atomics (count = run length),
-        // the others take the following positions.  Per record the atomics on a hot hash slot ran lane by lane: 64 % of this kernel's
-        // busy cycles were LDS bank-conflict cycles (profiles/r03_lds_bank_conflicts.txt).
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
-            const int bin = bin4[tp];
-            int nrun = 1, dist = 0;                 // run length (first lane of a run), distance to the run's first lane (others)
-            if (runs) {
-                const int pbin = __shfl_up(bin, 8);
-                const bool follow = bin >= 0 && lane64 >= 8 && pbin == bin;
-                const unsigned long long fm = __ballot(follow);
-                if (follow) {
-                    dist = 1;
-                    for (int k = lane64 - 8; k >= 8 && ((fm >> k) & 1ull); k -= 8) ++dist;
-                } else if (bin >= 0) {
-                    for (int k = lane64 + 8; k < 64 && ((fm >> k) & 1ull); k += 8) ++nrun;
-                }
-            }
-            unsigned cd = 0u;
-            if (bin >= 0 && dist == 0) {
-                int h = (int)(((unsigned)bin * 2654435761u) >> 24);
-                for (int probe = 0; probe < MSDA_HASH; ++probe) {
-                    const int prev = atomicCAS(&h_key[h], -1, bin);
-                    if (prev == -1 || prev == bin) { cd = 0x80000000u | ((unsigned)h << 16) | (unsigned)atomicAdd(&h_cnt[h], nrun); break; }
-                    h = (h + 1) & (MSDA_HASH - 1);
-                }
-                if (cd == 0u) cd = 0xc0000000u | ((unsigned)atomicAdd(bn.count + (long)bin * MSDA_CNT_STRIDE, nrun) & 0x3fffffffu);
-            }
-            if (runs) {
-                const unsigned lead = (unsigned)__shfl((int)cd, lane64 - 8 * dist);      // (the position fields cannot carry: < 2^16 records per
-                if (dist > 0) cd = lead + (unsigned)dist;                                //  workgroup and bin, < 2^30 per bin)
-            }
-            code[round][tp] = cd;
         }
     }
     __syncthreads();
